@@ -1,0 +1,263 @@
+#!/usr/bin/env python3
+"""Decode benchmark of the HIP path (contract in the task statement; metric from BASELINE.json).
+
+    python bench.py --gpus 1 --steps 256 --warmup 16
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+A *step* is one single-stream decode token of the workload (default: Llama-2-7B, GPTQ int4 g128, random-init
+synthetic weights of that architecture, 128-token synthetic prompt): one replay of the captured hipGraph.  With N > 1
+every rank is an independent replica on its own GPU with its own prompt (no collective on the data path —
+"replicas only"); the ranks only meet at the timing barriers.  ``value`` = tokens decoded by all ranks
+/ max over ranks of the wall time of the K steps.
+
+Besides the contract's fields the JSON line carries
+  roofline      for the dominant kernel: algorithmic bytes per launch / its mean duration, measured live with HIP
+                events taken from each dispatch (profiling sink of the library), against 8 TB/s;
+  step_roofline the same for the whole token (all algorithmic bytes / wall time per token) — includes launch gaps;
+  cpu_baseline  the CPU oracle (a port of the reference's generate()+model) timed on this host's cores on a bounded
+                sample of the same workload.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+from pathlib import Path
+
+import torch
+
+REPO = Path(__file__).resolve().parent
+if str(REPO) not in sys.path:
+    sys.path.insert(0, str(REPO))
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s spec, ~6.3 TB/s achievable)
+
+WORKLOADS = {
+    # name: (config, quantization mode, prompt length, kv window, dtype label)
+    "llama2-7b-int4": ("Llama-2-7b-hf", "gptq.int4-g128", 128, "u4 weights, bf16 activations, fp32 accumulate"),
+    "llama2-7b-int8": ("Llama-2-7b-hf", "bnb.int8", 128, "int8"),
+    "stablelm-3b-bf16": ("stablelm-base-alpha-3b", None, 512, "bf16"),
+    "falcon-40b-int4": ("falcon-40b", "gptq.int4-g128", 128, "u4 weights, bf16 activations, fp32 accumulate"),
+    "pythia-160m-bf16": ("pythia-160m", None, 128, "bf16"),
+    "tiny-llama-int4": ("tiny-llama", "gptq.int4-g128", 16, "u4 weights, bf16 activations, fp32 accumulate"),
+}
+
+
+def linear_bytes(cfg, mode):
+    """Algorithmic HBM bytes of each Linear per decoded token: every weight read once + quantisation
+    metadata.  Returns {linear name: bytes} for one block plus lm_head."""
+    out = {}
+    for name, (n, k) in cfg.linear_shapes().items():
+        if mode is None:
+            out[name] = n * k * 2
+        elif mode.startswith("gptq"):
+            group = 128 if mode.endswith("g128") else k
+            out[name] = n * k // 2 + n * (-(-k // group)) * 4  # packed nibbles + bf16 scale + bf16 zero per group
+        elif mode == "bnb.int8":
+            out[name] = n * k + n * 4  # int8 + fp32 SCB per row
+        else:
+            raise ValueError(mode)
+    return out
+
+
+def token_bytes(cfg, mode, context):
+    lb = linear_bytes(cfg, mode)
+    weights = sum(v for k, v in lb.items() if k != "lm_head") * cfg.n_layer + lb["lm_head"]
+    kv = 2 * cfg.n_query_groups * cfg.head_size * 2 * cfg.n_layer * context  # K and V rows 0..pos, GQA-native, bf16
+    return weights, kv + cfg.n_embd * 2
+
+
+def kernel_bytes_per_token(cfg, mode):
+    """Algorithmic bytes handled by each kernel id of the library during one token (for the roofline object)."""
+    lb = linear_bytes(cfg, mode)
+    L = cfg.n_layer
+    prefix = {None: "bf16_gemv", "bnb.int8": "w8_gemv"}.get(mode, "w4_gemv")
+    single = [k for k in lb if k not in ("mlp.fc_1", "mlp.fc_2", "lm_head")]
+    res = {prefix: (sum(lb[k] for k in single) * L + lb["lm_head"], len(single) * L + 1)}
+    if "mlp.fc_1" in lb:
+        dual = prefix if mode == "bnb.int8" else prefix + "_dual"
+        b, n = res.get(dual, (0, 0))
+        res[dual] = (b + (lb["mlp.fc_1"] + lb["mlp.fc_2"]) * L, n + L)
+    return res  # {kernel name: (bytes per token, launches per token)}
+
+
+def rank_env():
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    return rank, local, world
+
+
+def max_over_ranks(seconds: float, units: int, world: int, device) -> tuple:
+    """(max elapsed over ranks, total units over ranks).  The only collective of the benchmark (timing only)."""
+    if world == 1:
+        return seconds, units
+    import torch.distributed as dist
+
+    t = torch.tensor([seconds], dtype=torch.float64, device=device)
+    u = torch.tensor([units], dtype=torch.int64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dist.all_reduce(u, op=dist.ReduceOp.SUM)
+    return float(t.item()), int(u.item())
+
+
+def barrier(world: int, device) -> None:
+    if world > 1:
+        import torch.distributed as dist
+
+        dist.barrier(device_ids=[device.index] if device.type == "cuda" else None)
+    if device.type == "cuda":
+        torch.cuda.synchronize(device)
+
+
+def cpu_baseline(cfg, mode, model, prompt_cpu, budget_s: float = 20.0):
+    """Time the CPU oracle (port of the reference path) on a bounded sample: a short prompt prefix, then single-token
+    decode steps until ~budget_s of CPU work.  Returns the cpu_baseline object."""
+    from oracle import model as om
+
+    tile_cols = 128 if (mode or "").endswith("g128") else -1
+    sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
+    if mode == "bnb.int8":
+        return {"value": None, "unit": "tokens/s", "cores": torch.get_num_threads(), "kind": "port",
+                "sample": "skipped: int8 state dict holds only quantised weights"}
+    oracle = om.OracleGPT(cfg, sd, "gptq" if mode and mode.startswith("gptq") else "dense", tile_cols=tile_cols)
+    T0 = 4
+    S = T0 + 64
+    with torch.no_grad():
+        pos = torch.arange(T0)
+        logits = oracle(prompt_cpu[:T0].view(1, -1), S, pos)
+        n, t0 = 0, time.perf_counter()
+        while True:
+            tok = logits[0, -1].float().argmax().view(1, 1)
+            pos = pos[-1:] + 1
+            logits = oracle(tok, S, pos)
+            n += 1
+            el = time.perf_counter() - t0
+            if el > budget_s or n >= 60:
+                break
+    return {"value": n / el, "unit": "tokens/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{n} single-token decode steps after a {T0}-token prompt, same weights, oracle/model.py on the host CPU"}
+
+
+def main() -> None:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=256)
+    ap.add_argument("--warmup", type=int, default=16)
+    ap.add_argument("--workload", default="llama2-7b-int4", choices=sorted(WORKLOADS))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-budget", type=float, default=20.0)
+    args = ap.parse_args()
+
+    rank, local, world = rank_env()
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device: the decode path has no CPU fallback")
+    device = torch.device("cuda", local)
+    torch.cuda.set_device(device)
+    if world > 1:
+        import torch.distributed as dist
+
+        dist.init_process_group("nccl", device_id=device)
+
+    import lit_parrot_amd as L
+    from lit_parrot_amd import _hip
+    from lit_parrot_amd.config import Config
+    from lit_parrot_amd.generate.base import _session
+    from lit_parrot_amd.synth import build_synthetic_model, synthetic_prompt
+
+    cfg_name, mode, T, dtype_label = WORKLOADS[args.workload]
+    cfg = Config.from_name(cfg_name)
+    total = T + args.warmup + args.steps + 1
+    assert total <= cfg.block_size, "prompt + warmup + steps must fit block_size"
+    t_build = time.perf_counter()
+    model = build_synthetic_model(cfg, mode, seed=1234, device=device)
+    prompt = synthetic_prompt(cfg, T, seed=1234 + rank, device="cpu")
+    torch.cuda.synchronize(device)
+    t_build = time.perf_counter() - t_build
+
+    with torch.no_grad():
+        sess = _session(model, total, total, greedy=True)
+        t_pre = time.perf_counter()
+        logits = sess.prefill(prompt.to(device))
+        L.ops.argmax_advance(logits, sess.tokens, sess.pos)
+        torch.cuda.synchronize(device)
+        t_pre = time.perf_counter() - t_pre
+        sess.capture()
+        for _ in range(args.warmup):
+            sess.step()
+        barrier(world, device)
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            sess.step()
+        barrier(world, device)
+        elapsed = time.perf_counter() - t0
+        elapsed_max, units = max_over_ranks(elapsed, args.steps, world, device)
+        pos_end = int(sess.pos.item())
+        assert pos_end == T + args.warmup + args.steps, (pos_end, T, args.warmup, args.steps)
+
+        # per-kernel durations: the same step, launched eagerly with every dispatch bracketed by HIP events
+        prof_steps = 8
+        _hip.prof_begin()
+        for _ in range(prof_steps):
+            sess._step()
+        stats = _hip.prof_end()
+
+    ms_per_step = elapsed_max / args.steps * 1e3
+    ctx_mean = T + args.warmup + args.steps / 2.0
+    w_bytes, kv_bytes = token_bytes(cfg, mode, ctx_mean)
+    kb = kernel_bytes_per_token(cfg, mode)
+    dom = max(stats, key=lambda k: stats[k][0])
+    kernels = {k: {"avg_us": v[0] / v[1] * 1e3, "launches_per_token": v[1] / prof_steps, "ms_per_token": v[0] / prof_steps}
+               for k, v in sorted(stats.items(), key=lambda kv: -kv[1][0])}
+    roofline = None
+    if dom in kb:
+        bytes_per_launch = kb[dom][0] / kb[dom][1]
+        avg_s = stats[dom][0] / stats[dom][1] * 1e-3
+        achieved = bytes_per_launch / avg_s / 1e9
+        roofline = {"kernel": dom, "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": achieved / HBM_PEAK_GBS, "traffic": None, "bytes_per_launch": bytes_per_launch,
+                    "avg_launch_us": avg_s * 1e6, "launches_per_token": kb[dom][1]}
+    step_gbs = (w_bytes + kv_bytes) / (ms_per_step * 1e-3) / 1e9
+
+    result = {
+        "metric": "decode tokens/s (single-stream per GPU, independent replicas)",
+        "value": units / elapsed_max,
+        "unit": "tokens/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": ms_per_step,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": dtype_label,
+        "data": "synthetic",
+        "config": {"workload": f"{cfg_name} {mode or 'bf16'} single-stream decode, {T}-token prompt, random-init weights",
+                   "prompt_tokens": T, "replicas": world, "parallelism": f"replicas x{world} (no collective)",
+                   "graph": "hipGraph replay per token"},
+        "roofline": roofline,
+        "step_roofline": {"bound": "hbm", "achieved": step_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                          "frac": step_gbs / HBM_PEAK_GBS, "bytes_per_token": w_bytes + kv_bytes,
+                          "weight_bytes": w_bytes, "kv_bytes_mean_context": kv_bytes},
+        "kernels": kernels,
+        "prefill_ms": t_pre * 1e3,
+        "build_s": t_build,
+    }
+    if rank == 0:
+        if args.no_cpu_baseline or world > 1:
+            result["cpu_baseline"] = None
+        else:
+            result["cpu_baseline"] = cpu_baseline(cfg, mode, model, prompt, args.cpu_budget)
+        print(json.dumps(result), flush=True)
+    if world > 1:
+        import torch.distributed as dist
+
+        dist.barrier(device_ids=[device.index])
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

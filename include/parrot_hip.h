@@ -1,0 +1,137 @@
+/*
+ * parrot_hip.h — C ABI of libparrot_hip.so (gfx950 / MI355X).
+ *
+ * The drop-in boundary for the quantized-decode hot path of Lit-GPT
+ * (griff4692/lit-parrot).  The reference has no FFI of its own for this path:
+ * every op below is reached there through a PyTorch / Triton / bitsandbytes
+ * call.  Each entry point cites the reference call site it replaces
+ * (paths relative to the reference checkout).
+ *
+ * Conventions
+ *  - plain pointers and ints only; every pointer is a DEVICE pointer unless
+ *    its name ends in `_host`;
+ *  - the caller owns every buffer; the library never allocates or frees
+ *    tensor memory and keeps no mutable state besides the profiling sink;
+ *  - `stream` is a hipStream_t passed as void*; every call only enqueues work
+ *    on it (no synchronisation), so a call sequence can be hipGraph-captured;
+ *  - return value: 0 on success, negative PARROT_E* on failure; the message is
+ *    available from parrot_last_error() (thread local);
+ *  - "bf16" buffers hold IEEE bfloat16 bit patterns (uint16_t);
+ *  - "rows" (M) are token rows of the activation matrix, row m of `x` starts at
+ *    x + m*ldx elements.
+ */
+#ifndef PARROT_HIP_H
+#define PARROT_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PARROT_ABI_VERSION 1
+
+#define PARROT_OK 0
+#define PARROT_EINVAL (-1)       /* bad argument (shape, alignment, null pointer) */
+#define PARROT_EHIP (-2)         /* a HIP runtime call failed */
+#define PARROT_EUNSUPPORTED (-3) /* shape outside what the kernels are built for */
+
+/* epilogues of the GEMV/GEMM entry points */
+#define PARROT_EPI_NONE 0     /* out = bf16(acc + bias)                                   */
+#define PARROT_EPI_RESIDUAL 1 /* out = bf16(residual + bf16(acc + bias))  model.py:171,178-179 */
+#define PARROT_EPI_GELU 2     /* out = bf16(gelu_erf(bf16(acc + bias)))   model.py:284-287 */
+#define PARROT_EPI_SWIGLU 3   /* out = bf16(bf16(silu(bf16(acc1))) * bf16(acc2)) model.py:297-301 (needs 2nd weight) */
+
+int parrot_version(void);
+const char* parrot_last_error(void);
+
+/* ---- profiling sink (bench.py only): while enabled every kernel launch is
+ * bracketed by HIP events on its own stream (hipExtLaunchKernelGGL). ---------- */
+int parrot_prof_begin(void);
+/* synchronises, fills up to `cap` entries, returns the number of distinct kernels */
+int parrot_prof_end(int cap, int* kernel_ids_host, double* total_ms_host, int64_t* launches_host);
+const char* parrot_kernel_name(int kernel_id);
+
+/* ---- int4 (GPTQ format) -------------------------------------------------------
+ * Reference format (quantize/gptq.py:216-231): quant_weight uint8, logical
+ * (N, K/2) with strides (1, N) i.e. memory [K/2][N]; byte j of row o holds
+ * column 2j in the low nibble and 2j+1 in the high nibble (:240-241);
+ * scales/zeros (N, ceil(K/group)) bf16; w = (q - zero) * scale (:249-251).
+ * Kernel-native format "W4K": see DESIGN.md §3.                                   */
+int64_t parrot_w4_packed_bytes(int N, int K, int group);
+/* direction 0: reference -> W4K; 1: W4K -> reference (round trip is exact) */
+int parrot_w4_repack(void* quant_weight_ref, void* scales, void* zeros, int N, int K, int group,
+                     void* packed, int direction, void* stream);
+/* y[m, :] = epilogue(x[m, :] @ dequant(W).T)  — replaces ColBlockQuantizedLinear.forward
+ * (quantize/gptq.py:254-264) and qlinear_4bit_weight (:156-201) for M <= 8 rows.
+ * packed2 is the second weight of PARROT_EPI_SWIGLU (fc_2), else NULL.           */
+int parrot_w4_gemv(const void* packed, const void* packed2, const void* x, int ldx, int M,
+                   const void* bias, const void* residual, int ldr, void* out, int ldo, int N,
+                   int K, int group, int epilogue, void* stream);
+/* same contract for any M (prefill): MFMA path, dequant-to-LDS */
+int parrot_w4_gemm(const void* packed, const void* packed2, const void* x, int ldx, int M,
+                   const void* bias, const void* residual, int ldr, void* out, int ldo, int N,
+                   int K, int group, int epilogue, void* stream);
+
+/* ---- dense bf16 Linear (torch.nn.Linear on the bf16 path, lit_gpt/model.py:29,188,190,281-295)
+ * W is (N, K) row-major bf16.                                                    */
+int parrot_bf16_gemv(const void* W, const void* W2, const void* x, int ldx, int M, const void* bias,
+                     const void* residual, int ldr, void* out, int ldo, int N, int K, int epilogue,
+                     void* stream);
+int parrot_bf16_gemm(const void* W, const void* W2, const void* x, int ldx, int M, const void* bias,
+                     const void* residual, int ldr, void* out, int ldo, int N, int K, int epilogue,
+                     void* stream);
+
+/* ---- LLM.int8 (quantize/bnb.py:18-60; arithmetic = bitsandbytes MatMul8bitLt) ----
+ * quantize rows of a bf16/fp16-valued weight: CB = rne(127*W/absmax_row), SCB = absmax_row (fp32) */
+int parrot_w8_quantize_rows(const void* W_bf16, int N, int K, void* CB_int8, void* SCB_f32, void* stream);
+/* activation prep per token row: fp16-round x, mark |x| >= threshold as outliers
+ * (kept in 16-bit, zero in the int8 copy), absmax-quantise the rest.
+ * xq int8 [M][K]; xout fp32 [M][K] (the outlier values, 0 elsewhere); sca fp32 [M]; nout int32 [M] */
+int parrot_w8_prep_act(const void* x, int ldx, int M, int K, float threshold, void* xq, void* xout,
+                       void* sca, void* nout, void* stream);
+/* out = epilogue(cast_bf16(fp16(fp16(C32*SCA*SCB/127^2 + bias) + fp16(outlier_part)))).
+ * For PARROT_EPI_SWIGLU the second weight (fc_2) follows the first in the same buffers:
+ * CB holds 2N rows ([fc_1; fc_2]) and SCB 2N scales. */
+int parrot_w8_gemv(const void* CB, const void* SCB, const void* xq, const void* xout, const void* sca,
+                   const void* nout, int M, const void* bias, const void* residual, int ldr, void* out,
+                   int ldo, int N, int K, int epilogue, void* stream);
+
+/* ---- norms (lit_gpt/rmsnorm.py:17-21; torch.nn.LayerNorm via lit_gpt/config.py:86-92) ---- */
+int parrot_rmsnorm(const void* x, int ldx, const void* weight, void* out, int ldo, int M, int d,
+                   float eps, void* stream);
+int parrot_layernorm(const void* x, int ldx, const void* weight, const void* bias, void* out, int ldo,
+                     int M, int d, float eps, void* stream);
+
+/* ---- attention (lit_gpt/model.py:194-275, apply_rope :330-336) --------------------
+ * qkv: [M][n_groups*(q_per_kv+2)*hs] bf16, interleaved per group (model.py:208-214).
+ * rope_cos/sin: fp16 [rows][n_elem] (model.py:304-327); rope_local = 0: the full table, row m uses
+ * table row *pos + m; rope_local = 1: already indexed per row as Block.forward receives it
+ * (model.py:88-89), row m uses table row m.
+ * pos: device int32*, position of row 0 (row m is at *pos + m; rows are consecutive positions).
+ * k_cache/v_cache: bf16 [n_groups][S][hs] (GQA-native).  Slot = position % S,
+ * which is the reference's roll-left-and-append-last window (model.py:238-245)
+ * up to the order of the slots.                                                   */
+int parrot_qkv_rope_kvappend(const void* qkv, int ldqkv, int M, const void* rope_cos,
+                             const void* rope_sin, int n_elem, int rope_local, const int32_t* pos, int n_groups,
+                             int q_per_kv, int hs, int S, void* q_out, void* k_cache, void* v_cache,
+                             void* stream);
+/* y[m] = softmax(q[m] k^T / sqrt(hs)) v over slots 0..min(*pos+m, S-1); y: [M][n_head*hs] bf16.
+ * workspace: fp32, at least parrot_attn_workspace_floats(...) elements.              */
+int64_t parrot_attn_workspace_floats(int M, int n_head, int hs, int nsplit);
+int parrot_attn_decode(const void* q, int M, const int32_t* pos, const void* k_cache,
+                       const void* v_cache, int n_groups, int q_per_kv, int hs, int S, int nsplit,
+                       void* workspace, void* y, int ldy, void* stream);
+
+/* ---- small ops of the step ----------------------------------------------------------
+ * x[m] = wte[tokens[(pos ? *pos : 0) + m]]   (lit_gpt/model.py:99)                    */
+int parrot_embedding(const void* wte, int d, const int64_t* tokens, const int32_t* pos, int M,
+                     void* out, int ldo, void* stream);
+/* greedy step of generate() (generate/base.py:136-153 with top_k=1):
+ * tokens[*pos + 1] = argmax(logits) (lowest index on ties); then *pos += 1.          */
+int parrot_argmax_advance(const void* logits, int V, int64_t* tokens, int32_t* pos, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PARROT_HIP_H */

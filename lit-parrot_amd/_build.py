@@ -1,0 +1,50 @@
+"""Compile the HIP sources of this package into ``libparrot_hip.so`` (gfx950 only, in-tree).
+
+``hipcc`` cross-compiles without a GPU, so this runs in the build container as well as on the GPU box.
+"""
+import os
+import shutil
+import subprocess
+from pathlib import Path
+
+PKG_DIR = Path(__file__).resolve().parent
+CSRC = PKG_DIR / "csrc"
+LIB_PATH = PKG_DIR / "libparrot_hip.so"
+SOURCES = ["core.hip", "w4.hip", "dense.hip", "w8.hip", "norm.hip", "attn.hip", "misc.hip", "gemm.hip", "prefill_attn.hip"]
+ARCH = "gfx950"
+
+
+def _hipcc() -> str:
+    exe = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(exe):
+        raise RuntimeError("hipcc not found: the HIP extension cannot be built")
+    return exe
+
+
+def needs_build() -> bool:
+    if not LIB_PATH.exists():
+        return True
+    newest = max(p.stat().st_mtime for p in list(CSRC.glob("*.hip")) + list(CSRC.glob("*.h")) +
+                 [PKG_DIR.parent / "include" / "parrot_hip.h"])
+    return newest > LIB_PATH.stat().st_mtime
+
+
+def build(force: bool = False, verbose: bool = False) -> Path:
+    """Build libparrot_hip.so if it is missing or older than its sources."""
+    if not force and not needs_build():
+        return LIB_PATH
+    srcs = [str(CSRC / s) for s in SOURCES if (CSRC / s).exists()]
+    tmp = LIB_PATH.with_suffix(".so.tmp")
+    cmd = [_hipcc(), f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-shared", "-fgpu-rdc" if False else "-fno-gpu-rdc",
+           "-Wall", "-Wno-unused-function", "-o", str(tmp)] + srcs
+    if verbose:
+        print(" ".join(cmd))
+    proc = subprocess.run(cmd, capture_output=True, text=True)
+    if proc.returncode != 0:
+        raise RuntimeError(f"hipcc failed:\n{proc.stdout}\n{proc.stderr}")
+    os.replace(tmp, LIB_PATH)
+    return LIB_PATH
+
+
+if __name__ == "__main__":
+    print(build(force=True, verbose=True))

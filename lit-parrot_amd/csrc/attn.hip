@@ -1,0 +1,277 @@
+// CausalSelfAttention without the two Linears (lit_gpt/model.py:194-275):
+//   qkv_rope_kvappend : per-group q/k/v split (:208-214), partial RoPE (:226-232, apply_rope :330-336),
+//                       KV-cache write (:243-245).  GQA is stored natively: one K/V head per query group
+//                       (the reference expands K/V to n_head with repeat_interleave, :217-220).
+//   attn_decode       : softmax(q k^T / sqrt(hs)) v over the cached slots the causal mask admits
+//                       (:256-275 with the mask rows built at :88-92), flash-decoding style split over the
+//                       sequence + a combine pass.
+//
+// Cache layout: [n_groups][S][hs] bf16.  Slot of position p is p % S: when p >= S this overwrites the oldest
+// entry, which is what the reference's roll-left + write-last does (:238-245) up to slot order.
+//
+// Decode attention is memory-bound on K/V rows.  A K (or V) row of hs bf16 is read by hs/8 lanes with one
+// 16-B load each, so one wave instruction covers 64*8/hs rows (1 KiB contiguous); scores are reduced over
+// those lanes with shuffles; every (wave, row-slot) keeps its own online-softmax state (m, l, acc[8]) in
+// registers and the states are merged once at the end through LDS.
+#include <hip/hip_fp16.h>
+
+#include "parrot_common.h"
+
+namespace parrot {
+
+// ------------------------------------------------------------------------------------------ rope + kv append
+// one thread per (row m, head-slot j in [0, n_groups*(q_per_kv+2)), pair index i in [0, hs/2))
+__global__ void __launch_bounds__(256)
+rope_kvappend_kernel(const bf16_t* __restrict__ qkv, int ldqkv, int M, const __half* __restrict__ rope_cos,
+                     const __half* __restrict__ rope_sin, int n_elem, int rope_local, const int32_t* __restrict__ pos_ptr, int n_groups,
+                     int q_per_kv, int hs, int S, bf16_t* __restrict__ q_out, bf16_t* __restrict__ k_cache,
+                     bf16_t* __restrict__ v_cache) {
+    const int half_hs = hs >> 1;
+    const int per_group = q_per_kv + 2;
+    const int slots = n_groups * per_group;
+    const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int i = (int)(tid % half_hs);
+    const int j = (int)((tid / half_hs) % slots);
+    const int m = (int)(tid / ((int64_t)half_hs * slots));
+    if (m >= M) return;
+    const int g = j / per_group, t = j % per_group;  // t < q_per_kv: query head; == q_per_kv: key; else value
+    const int pos = pos_ptr[0] + m;
+    const bf16_t* src = qkv + (int64_t)m * ldqkv + (int64_t)j * hs;
+    bf16_t* dst;
+    if (t < q_per_kv)
+        dst = q_out + ((int64_t)m * n_groups * q_per_kv + (int64_t)g * q_per_kv + t) * hs;
+    else if (t == q_per_kv)
+        dst = k_cache + ((int64_t)g * S + (pos % S)) * hs;
+    else
+        dst = v_cache + ((int64_t)g * S + (pos % S)) * hs;
+
+    const int half_n = n_elem >> 1;
+    // element pair handled by this thread: (i, i + half_n) inside the rotary part, or two pass-through dims
+    if (t <= q_per_kv && i < half_n) {
+        const float x1 = bf2f(src[i]), x2 = bf2f(src[i + half_n]);
+        const int64_t rrow = rope_local ? m : pos;  // tables pre-indexed per row (Block.forward callers) or absolute
+        const float c1 = __half2float(rope_cos[rrow * n_elem + i]);
+        const float s1 = __half2float(rope_sin[rrow * n_elem + i]);
+        const float c2 = __half2float(rope_cos[rrow * n_elem + i + half_n]);
+        const float s2 = __half2float(rope_sin[rrow * n_elem + i + half_n]);
+        // roped = x*cos + rotate_half(x)*sin, every product and the sum rounded to fp32 separately (no FMA),
+        // as the reference's promoted bf16*fp16 tensor ops do (model.py:330-336)
+        const float o1 = __fadd_rn(__fmul_rn(x1, c1), __fmul_rn(-x2, s1));
+        const float o2 = __fadd_rn(__fmul_rn(x2, c2), __fmul_rn(x1, s2));
+        dst[i] = f2bf(o1);
+        dst[i + half_n] = f2bf(o2);
+    } else {
+        // pass-through: value heads entirely, and dims >= n_elem of q/k.  Thread i covers 2 dims.
+        const int base = (t <= q_per_kv) ? n_elem : 0;
+        const int idx = (t <= q_per_kv) ? (i - half_n) * 2 : i * 2;
+        dst[base + idx] = src[base + idx];
+        dst[base + idx + 1] = src[base + idx + 1];
+    }
+}
+
+// ------------------------------------------------------------------------------------------ decode attention
+constexpr int kAttnWaves = 4;
+
+// partial state layout in the workspace: [M][n_head][nsplit][hs + 2] floats: acc[hs], m, l
+// HQ = query heads of the group processed in one pass over the K/V rows (1 for MHA, up to 4 for GQA/MQA)
+template <int HS, int HQ>
+__global__ void __launch_bounds__(kAttnWaves * 64)
+attn_decode_kernel(const bf16_t* __restrict__ q, const int32_t* __restrict__ pos_ptr, const bf16_t* __restrict__ k_cache,
+                   const bf16_t* __restrict__ v_cache, int n_groups, int q_per_kv, int S, int nsplit,
+                   float* __restrict__ ws, bf16_t* __restrict__ y, int ldy) {
+    constexpr int LPR = HS / 8;    // lanes per K/V row
+    constexpr int RPW = 64 / LPR;  // rows per wave instruction
+    constexpr int NSLOT = kAttnWaves * RPW;
+    __shared__ float sh_acc[HQ][NSLOT][HS];
+    __shared__ float sh_m[HQ][NSLOT], sh_l[HQ][NSLOT];
+
+    const int g = blockIdx.x, split = blockIdx.y, m = blockIdx.z;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int sub = lane / LPR, dl = lane % LPR;
+    const int n_head = n_groups * q_per_kv;
+    const int pos = pos_ptr[0] + m;
+    const int n_valid = min(pos + 1, S);  // slots 0..n_valid-1 hold the admitted keys
+    const int per = (S + nsplit - 1) / nsplit;
+    const int s_begin = split * per, s_end = min(n_valid, s_begin + per);
+    const float scale = 1.0f / sqrtf((float)HS);
+    const uint4* kc = reinterpret_cast<const uint4*>(k_cache + (int64_t)g * S * HS);
+    const uint4* vc = reinterpret_cast<const uint4*>(v_cache + (int64_t)g * S * HS);
+    const int slot = wave * RPW + sub;
+
+    for (int h0 = 0; h0 < q_per_kv; h0 += HQ) {
+        float qf[HQ][8];
+        float mrun[HQ], lrun[HQ], acc[HQ][8];
+#pragma unroll
+        for (int hh = 0; hh < HQ; ++hh) {
+            const int head = g * q_per_kv + min(h0 + hh, q_per_kv - 1);
+            const uint4 qv = reinterpret_cast<const uint4*>(q + ((int64_t)m * n_head + head) * HS)[dl];
+            const uint32_t dw[4] = {qv.x, qv.y, qv.z, qv.w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                qf[hh][2 * j] = bflo(dw[j]) * scale;
+                qf[hh][2 * j + 1] = bfhi(dw[j]) * scale;
+            }
+            mrun[hh] = -INFINITY;
+            lrun[hh] = 0.f;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[hh][e] = 0.f;
+        }
+        for (int s0 = s_begin + wave * RPW; s0 < s_end; s0 += kAttnWaves * RPW) {
+            const int s = s0 + sub;
+            const bool ok = s < s_end;
+            const int sc = ok ? s : s_end - 1;
+            const uint4 kv = kc[(int64_t)sc * LPR + dl];
+            const uint4 vv = vc[(int64_t)sc * LPR + dl];
+            const uint32_t kd[4] = {kv.x, kv.y, kv.z, kv.w};
+            const uint32_t vd[4] = {vv.x, vv.y, vv.z, vv.w};
+            float kf[8], vf[8];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                kf[2 * j] = bflo(kd[j]);
+                kf[2 * j + 1] = bfhi(kd[j]);
+                vf[2 * j] = bflo(vd[j]);
+                vf[2 * j + 1] = bfhi(vd[j]);
+            }
+#pragma unroll
+            for (int hh = 0; hh < HQ; ++hh) {
+                float sc_ = 0.f;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) sc_ = fmaf(qf[hh][e], kf[e], sc_);
+#pragma unroll
+                for (int off = LPR / 2; off >= 1; off >>= 1) sc_ += __shfl_xor(sc_, off, 64);
+                if (ok) {
+                    const float mn = fmaxf(mrun[hh], sc_);
+                    const float corr = __expf(mrun[hh] - mn);  // exp(-inf) = 0 on the first key
+                    const float p = __expf(sc_ - mn);
+                    lrun[hh] = lrun[hh] * corr + p;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) acc[hh][e] = acc[hh][e] * corr + p * vf[e];
+                    mrun[hh] = mn;
+                }
+            }
+        }
+        // publish every (wave, row-slot) state, then merge: thread d of head hh sums over the slots
+        __syncthreads();
+#pragma unroll
+        for (int hh = 0; hh < HQ; ++hh) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) sh_acc[hh][slot][dl * 8 + e] = acc[hh][e];
+            if (dl == 0) {
+                sh_m[hh][slot] = mrun[hh];
+                sh_l[hh][slot] = lrun[hh];
+            }
+        }
+        __syncthreads();
+        for (int idx = threadIdx.x; idx < HQ * HS; idx += kAttnWaves * 64) {
+            const int hh = idx / HS, d = idx % HS;
+            if (h0 + hh < q_per_kv) {
+                float mx = -INFINITY;
+                for (int t = 0; t < NSLOT; ++t) mx = fmaxf(mx, sh_m[hh][t]);
+                float l = 0.f, a = 0.f;
+                for (int t = 0; t < NSLOT; ++t) {
+                    const float mt = sh_m[hh][t];
+                    const float w = (mt == -INFINITY) ? 0.f : __expf(mt - mx);
+                    l += sh_l[hh][t] * w;
+                    a += sh_acc[hh][t][d] * w;
+                }
+                const int head = g * q_per_kv + h0 + hh;
+                if (nsplit == 1) {
+                    y[(int64_t)m * ldy + (int64_t)head * HS + d] = f2bf(a / l);
+                } else {
+                    float* p = ws + (((int64_t)m * n_head + head) * nsplit + split) * (HS + 2);
+                    p[d] = a;
+                    if (d == 0) {
+                        p[HS] = mx;
+                        p[HS + 1] = l;
+                    }
+                }
+            }
+        }
+    }
+}
+
+// merge the nsplit partial states of one (row, head); one thread per output dim
+template <int HS>
+__global__ void __launch_bounds__(HS)
+attn_combine_kernel(const float* __restrict__ ws, int nsplit, bf16_t* __restrict__ y, int ldy, int n_head) {
+    const int head = blockIdx.x, m = blockIdx.y, d = threadIdx.x;
+    const float* p = ws + ((int64_t)m * n_head + head) * nsplit * (HS + 2);
+    float mx = -INFINITY;
+    for (int t = 0; t < nsplit; ++t) mx = fmaxf(mx, p[t * (HS + 2) + HS]);
+    float l = 0.f, a = 0.f;
+    for (int t = 0; t < nsplit; ++t) {
+        const float mt = p[t * (HS + 2) + HS];
+        const float w = (mt == -INFINITY) ? 0.f : __expf(mt - mx);
+        l += p[t * (HS + 2) + HS + 1] * w;
+        a += p[t * (HS + 2) + d] * w;
+    }
+    y[(int64_t)m * ldy + (int64_t)head * HS + d] = f2bf(a / l);
+}
+
+template <int HS>
+static int attn_launch(const void* q, int M, const int32_t* pos, const void* k_cache, const void* v_cache, int n_groups,
+                       int q_per_kv, int S, int nsplit, void* ws, void* y, int ldy, hipStream_t st) {
+    const dim3 grid(n_groups, nsplit, M), block(kAttnWaves * 64);
+    int rc;
+#define PARROT_ATTN_GO(HQV)                                                                                          \
+    rc = launch(K_ATTN_DECODE, attn_decode_kernel<HS, HQV>, grid, block, 0, st, (const bf16_t*)q, pos,                \
+                (const bf16_t*)k_cache, (const bf16_t*)v_cache, n_groups, q_per_kv, S, nsplit, (float*)ws, (bf16_t*)y, ldy)
+    if (q_per_kv == 1) {
+        PARROT_ATTN_GO(1);
+    } else if (q_per_kv == 2) {
+        PARROT_ATTN_GO(2);
+    } else {
+        PARROT_ATTN_GO(4);
+    }
+#undef PARROT_ATTN_GO
+    if (rc != PARROT_OK || nsplit == 1) return rc;
+    return launch(K_ATTN_COMBINE, attn_combine_kernel<HS>, dim3(n_groups * q_per_kv, M), dim3(HS), 0, st, (const float*)ws,
+                  nsplit, (bf16_t*)y, ldy, n_groups * q_per_kv);
+}
+
+}  // namespace parrot
+
+using namespace parrot;
+
+extern "C" {
+
+int parrot_qkv_rope_kvappend(const void* qkv, int ldqkv, int M, const void* rope_cos, const void* rope_sin, int n_elem,
+                             int rope_local, const int32_t* pos, int n_groups, int q_per_kv, int hs, int S, void* q_out, void* k_cache,
+                             void* v_cache, void* stream) {
+    PARROT_REQUIRE(qkv && pos && q_out && k_cache && v_cache, "qkv_rope_kvappend: null pointer");
+    PARROT_REQUIRE(M >= 1 && n_groups >= 1 && q_per_kv >= 1 && hs >= 2 && S >= 1, "qkv_rope_kvappend: bad shape");
+    PARROT_REQUIRE(hs % 2 == 0 && n_elem % 2 == 0 && n_elem >= 0 && n_elem <= hs,
+                   "qkv_rope_kvappend: hs=%d and n_elem=%d must be even, n_elem <= hs", hs, n_elem);
+    PARROT_REQUIRE(n_elem == 0 || (rope_cos && rope_sin), "qkv_rope_kvappend: rope tables missing");
+    PARROT_REQUIRE(ldqkv >= n_groups * (q_per_kv + 2) * hs, "qkv_rope_kvappend: ldqkv too small");
+    PARROT_REQUIRE(M <= S, "qkv_rope_kvappend: M=%d rows do not fit a cache of %d slots", M, S);
+    const int64_t total = (int64_t)M * n_groups * (q_per_kv + 2) * (hs / 2);
+    return launch(K_ROPE_KVAPPEND, rope_kvappend_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
+                  (hipStream_t)stream, (const bf16_t*)qkv, ldqkv, M, (const __half*)rope_cos, (const __half*)rope_sin,
+                  n_elem, rope_local, pos, n_groups, q_per_kv, hs, S, (bf16_t*)q_out, (bf16_t*)k_cache, (bf16_t*)v_cache);
+}
+
+int64_t parrot_attn_workspace_floats(int M, int n_head, int hs, int nsplit) {
+    return (int64_t)M * n_head * nsplit * (hs + 2);
+}
+
+int parrot_attn_decode(const void* q, int M, const int32_t* pos, const void* k_cache, const void* v_cache, int n_groups,
+                       int q_per_kv, int hs, int S, int nsplit, void* workspace, void* y, int ldy, void* stream) {
+    PARROT_REQUIRE(q && pos && k_cache && v_cache && y, "attn_decode: null pointer");
+    PARROT_REQUIRE(M >= 1 && n_groups >= 1 && q_per_kv >= 1 && S >= 1, "attn_decode: bad shape");
+    PARROT_REQUIRE(nsplit >= 1 && nsplit <= 65535 && M <= 65535, "attn_decode: nsplit/M out of range");
+    PARROT_REQUIRE(nsplit == 1 || workspace, "attn_decode: workspace required when nsplit > 1");
+    PARROT_REQUIRE(ldy >= n_groups * q_per_kv * hs, "attn_decode: ldy too small");
+    PARROT_REQUIRE(aligned16(q) && aligned16(k_cache) && aligned16(v_cache), "attn_decode: q/k/v must be 16-byte aligned");
+    hipStream_t st = (hipStream_t)stream;
+    switch (hs) {
+        case 32: return attn_launch<32>(q, M, pos, k_cache, v_cache, n_groups, q_per_kv, S, nsplit, workspace, y, ldy, st);
+        case 64: return attn_launch<64>(q, M, pos, k_cache, v_cache, n_groups, q_per_kv, S, nsplit, workspace, y, ldy, st);
+        case 128: return attn_launch<128>(q, M, pos, k_cache, v_cache, n_groups, q_per_kv, S, nsplit, workspace, y, ldy, st);
+        default: break;
+    }
+    set_error("attn_decode: head size %d not built (32, 64, 128)", hs);
+    return PARROT_EUNSUPPORTED;
+}
+
+}  // extern "C"

@@ -1,0 +1,86 @@
+// Small ops of the decode step: token embedding gather and the greedy sampling step.
+#include "parrot_common.h"
+
+namespace parrot {
+
+// x[m] = wte[tokens[base + m]]  (lit_gpt/model.py:99); 16-B copies
+__global__ void __launch_bounds__(256)
+embedding_kernel(const uint4* __restrict__ wte, int d16, const int64_t* __restrict__ tokens,
+                 const int32_t* __restrict__ pos_ptr, uint4* __restrict__ out, int ldo16) {
+    const int m = blockIdx.y;
+    const int64_t base = pos_ptr ? (int64_t)pos_ptr[0] : 0;
+    const int64_t tok = tokens[base + m];
+    for (int c = blockIdx.x * blockDim.x + threadIdx.x; c < d16; c += gridDim.x * blockDim.x)
+        out[(int64_t)m * ldo16 + c] = wte[tok * d16 + c];
+}
+
+// generate/base.py:136-153 with temperature > 0 and top_k = 1: the sampled token is the arg-max of the logits.
+// (The reference draws from a one-hot multinomial; with tied maxima it picks one of them at random, here the
+// lowest index wins.)  Single workgroup; then the loop state advances: tokens[pos+1] = best, pos += 1.
+constexpr int kArgmaxThreads = 1024;
+__global__ void __launch_bounds__(kArgmaxThreads)
+argmax_advance_kernel(const bf16_t* __restrict__ logits, int V, int64_t* __restrict__ tokens, int32_t* __restrict__ pos_ptr) {
+    __shared__ float sv[kArgmaxThreads / 64];
+    __shared__ int si[kArgmaxThreads / 64];
+    float best = -INFINITY;
+    int bi = 0x7fffffff;
+    for (int i = threadIdx.x; i < V; i += kArgmaxThreads) {
+        float v = bf2f(logits[i]);
+        if (v != v) v = -INFINITY;  // a NaN logit never wins
+        if (bi == 0x7fffffff || v > best) {  // indices ascend per thread, so ties keep the lowest
+            best = v;
+            bi = i;
+        }
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        const float ov = __shfl_xor(best, off, 64);
+        const int oi = __shfl_xor(bi, off, 64);
+        if (ov > best || (ov == best && oi < bi)) {
+            best = ov;
+            bi = oi;
+        }
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) {
+        sv[wave] = best;
+        si[wave] = bi;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < kArgmaxThreads / 64; ++w)
+            if (sv[w] > best || (sv[w] == best && si[w] < bi)) {
+                best = sv[w];
+                bi = si[w];
+            }
+        const int pos = pos_ptr[0];
+        tokens[pos + 1] = (bi == 0x7fffffff) ? 0 : bi;
+        pos_ptr[0] = pos + 1;
+    }
+}
+
+}  // namespace parrot
+
+using namespace parrot;
+
+extern "C" {
+
+int parrot_embedding(const void* wte, int d, const int64_t* tokens, const int32_t* pos, int M, void* out, int ldo,
+                     void* stream) {
+    PARROT_REQUIRE(wte && tokens && out, "embedding: null pointer");
+    PARROT_REQUIRE(M >= 1 && M <= 65535 && d >= 8 && d % 8 == 0 && ldo % 8 == 0 && ldo >= d,
+                   "embedding: d and ldo must be multiples of 8 (d=%d ldo=%d M=%d)", d, ldo, M);
+    PARROT_REQUIRE(aligned16(wte) && aligned16(out), "embedding: pointers must be 16-byte aligned");
+    const int d16 = d / 8;
+    return launch(K_EMBEDDING, embedding_kernel, dim3((d16 + 255) / 256, M), dim3(256), 0, (hipStream_t)stream,
+                  (const uint4*)wte, d16, tokens, pos, (uint4*)out, ldo / 8);
+}
+
+int parrot_argmax_advance(const void* logits, int V, int64_t* tokens, int32_t* pos, void* stream) {
+    PARROT_REQUIRE(logits && tokens && pos, "argmax_advance: null pointer");
+    PARROT_REQUIRE(V >= 1, "argmax_advance: V=%d", V);
+    return launch(K_ARGMAX, argmax_advance_kernel, dim3(1), dim3(kArgmaxThreads), 0, (hipStream_t)stream,
+                  (const bf16_t*)logits, V, tokens, pos);
+}
+
+}  // extern "C"

@@ -1,0 +1,152 @@
+// Shared device/host helpers for libparrot_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
+#include <stdint.h>
+#include <vector>
+
+#include "../../include/parrot_hip.h"
+
+namespace parrot {
+
+// ---------------------------------------------------------------- errors
+void set_error(const char* fmt, ...);
+int hip_fail(hipError_t e, const char* what);
+
+#define PARROT_REQUIRE(cond, ...)                 \
+    do {                                          \
+        if (!(cond)) {                            \
+            ::parrot::set_error(__VA_ARGS__);     \
+            return PARROT_EINVAL;                 \
+        }                                         \
+    } while (0)
+
+#define PARROT_UNSUPPORTED(cond, ...)             \
+    do {                                          \
+        if (!(cond)) {                            \
+            ::parrot::set_error(__VA_ARGS__);     \
+            return PARROT_EUNSUPPORTED;           \
+        }                                         \
+    } while (0)
+
+inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+// argument checks shared by every Linear-shaped entry point
+inline int check_linear_args(const char* who, const void* W, const void* W2, const void* x, int ldx, int M,
+                             const void* residual, int ldr, const void* out, int ldo, int N, int K, int epi) {
+    PARROT_REQUIRE(W && x && out, "%s: null pointer", who);
+    PARROT_REQUIRE(M >= 1 && N >= 1 && K >= 1, "%s: bad shape M=%d N=%d K=%d", who, M, N, K);
+    PARROT_REQUIRE(epi >= PARROT_EPI_NONE && epi <= PARROT_EPI_SWIGLU, "%s: unknown epilogue %d", who, epi);
+    PARROT_REQUIRE((epi == PARROT_EPI_SWIGLU) == (W2 != nullptr), "%s: second weight iff SWIGLU", who);
+    PARROT_REQUIRE((epi == PARROT_EPI_RESIDUAL) == (residual != nullptr), "%s: residual iff RESIDUAL epilogue", who);
+    PARROT_REQUIRE(ldx >= K && ldo >= N && (!residual || ldr >= N), "%s: leading dimension too small", who);
+    PARROT_REQUIRE(aligned16(W) && aligned16(x) && (ldx % 8 == 0) && (!W2 || aligned16(W2)),
+                   "%s: W and x must be 16-byte aligned, ldx a multiple of 8", who);
+    return PARROT_OK;
+}
+
+// ---------------------------------------------------------------- kernel ids (profiling sink)
+enum KernelId : int {
+    K_W4_GEMV = 0,
+    K_W4_GEMV_DUAL,
+    K_W4_REPACK,
+    K_BF16_GEMV,
+    K_BF16_GEMV_DUAL,
+    K_W8_QUANT_ROWS,
+    K_W8_PREP_ACT,
+    K_W8_GEMV,
+    K_RMSNORM,
+    K_LAYERNORM,
+    K_ROPE_KVAPPEND,
+    K_ATTN_DECODE,
+    K_ATTN_COMBINE,
+    K_EMBEDDING,
+    K_ARGMAX,
+    K_W4_GEMM,
+    K_BF16_GEMM,
+    K_COUNT
+};
+
+struct ProfRecord {
+    int kid;
+    hipEvent_t start, stop;
+};
+struct ProfSink {
+    bool enabled = false;
+    std::vector<ProfRecord> records;
+};
+ProfSink& prof_sink();
+
+// Launch through one place so that the profiling sink can bracket each launch with
+// HIP events taken from the dispatch packet itself (hipExtLaunchKernelGGL).
+template <typename... KArgs, typename... Args>
+inline int launch(int kid, void (*kern)(KArgs...), dim3 grid, dim3 block, size_t shmem,
+                  hipStream_t st, Args... args) {
+    ProfSink& ps = prof_sink();
+    if (ps.enabled) {
+        ProfRecord r;
+        r.kid = kid;
+        if (hipEventCreate(&r.start) != hipSuccess || hipEventCreate(&r.stop) != hipSuccess)
+            return hip_fail(hipGetLastError(), "hipEventCreate");
+        hipExtLaunchKernelGGL(kern, grid, block, shmem, st, r.start, r.stop, 0, static_cast<KArgs>(args)...);
+        ps.records.push_back(r);
+    } else {
+        hipLaunchKernelGGL(kern, grid, block, shmem, st, static_cast<KArgs>(args)...);
+    }
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return hip_fail(e, "kernel launch");
+    return PARROT_OK;
+}
+
+// ---------------------------------------------------------------- device helpers
+typedef uint16_t bf16_t;  // raw bfloat16 bits
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2_t;
+
+__device__ __forceinline__ float bf2f(bf16_t v) { return __uint_as_float(static_cast<uint32_t>(v) << 16); }
+__device__ __forceinline__ float bflo(uint32_t packed) { return __uint_as_float(packed << 16); }
+__device__ __forceinline__ float bfhi(uint32_t packed) { return __uint_as_float(packed & 0xffff0000u); }
+// round-to-nearest-even, NaN preserving (v_cvt_pk_bf16_f32 on gfx950)
+__device__ __forceinline__ bf16_t f2bf(float f) {
+    __bf16 b = static_cast<__bf16>(f);
+    return __builtin_bit_cast(bf16_t, b);
+}
+// round a float to bf16 precision and come back (the reference's per-op bf16 rounding points)
+__device__ __forceinline__ float rbf(float f) { return bf2f(f2bf(f)); }
+
+__device__ __forceinline__ float dot2_bf16(uint32_t a, uint32_t b, float acc) {
+    return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, a), __builtin_bit_cast(bf16x2_t, b),
+                                           acc, false);
+}
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 64));
+    return v;
+}
+
+// gelu(x) = 0.5 x (1 + erf(x / sqrt(2))) — torch.nn.functional.gelu default ("none" approximation)
+__device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+__device__ __forceinline__ float silu(float x) { return x / (1.0f + expf(-x)); }
+
+// shared GEMV epilogue: acc is the fp32 dot product (bias not yet added)
+__device__ __forceinline__ bf16_t apply_epilogue(int epi, float acc, float acc2, const bf16_t* bias,
+                                                 const bf16_t* residual, int col) {
+    float v = acc;
+    if (bias != nullptr) v += bf2f(bias[col]);
+    v = rbf(v);
+    if (epi == PARROT_EPI_RESIDUAL) {
+        v = bf2f(residual[col]) + v;
+    } else if (epi == PARROT_EPI_GELU) {
+        v = gelu_erf(v);
+    } else if (epi == PARROT_EPI_SWIGLU) {
+        v = rbf(silu(v)) * rbf(acc2);
+    }
+    return f2bf(v);
+}
+
+}  // namespace parrot

@@ -1,0 +1,234 @@
+// LLM.int8 Linear (quantize/bnb.py:18-60).  The arithmetic lives in the third-party bitsandbytes wheel
+// (>= 0.40.0, not vendored in the reference); this file restates the published algorithm as configured
+// there (has_fp16_weights=False, threshold=6.0):
+//   weights   : CB = rint(127 * fp16(W) / absmax_row) int8, SCB = absmax_row            (double_quant, bnb.py:55)
+//   per token : A = fp16(x); columns with |A| >= threshold are outliers: they are zero in the int8 copy and
+//               excluded from the row absmax; CA = rint(127 * A / absmax_row), SCA = absmax_row
+//   product   : C32 = CA . CB^T (int32);  out16 = fp16(C32 * (1/127^2) * SCA * SCB + bias)      (mm_dequant)
+//   outliers  : out16 = fp16(out16 + fp16(sum_k A[k] * fp16(CB[o,k] * SCB[o] / 127)))          (mixed decomposition)
+//   result    : cast back to the input dtype (bf16), then the layer's epilogue.
+// Rows of a multi-row call are treated independently (== M separate single-token calls).
+#include <hip/hip_fp16.h>
+
+#include "parrot_common.h"
+
+namespace parrot {
+
+__device__ __forceinline__ float rhalf(float v) { return __half2float(__float2half(v)); }
+constexpr float kMmDequant = 6.200012e-05f;  // 1 / (127 * 127)
+
+__device__ __forceinline__ float block_max_256(float v, float* sh) {
+    v = wave_max(v);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) sh[wave] = v;
+    __syncthreads();
+    return fmaxf(fmaxf(sh[0], sh[1]), fmaxf(sh[2], sh[3]));
+}
+
+// one workgroup (256 threads) per weight row
+__global__ void __launch_bounds__(256)
+w8_quantize_rows_kernel(const bf16_t* __restrict__ W, int K, int8_t* __restrict__ CB, float* __restrict__ SCB) {
+    __shared__ float sh[4];
+    const bf16_t* w = W + (int64_t)blockIdx.x * K;
+    float mx = 0.f;
+    for (int k = threadIdx.x; k < K; k += 256) mx = fmaxf(mx, fabsf(rhalf(bf2f(w[k]))));
+    mx = block_max_256(mx, sh);
+    const float inv = mx > 0.f ? 127.0f / mx : 0.f;
+    for (int k = threadIdx.x; k < K; k += 256)
+        CB[(int64_t)blockIdx.x * K + k] = (int8_t)rintf(rhalf(bf2f(w[k])) * inv);
+    if (threadIdx.x == 0) SCB[blockIdx.x] = mx;
+}
+
+// one workgroup per token row.  oidx is the compact list of outlier columns (capacity K per row).
+__global__ void __launch_bounds__(256)
+w8_prep_act_kernel(const bf16_t* __restrict__ x, int ldx, int K, float threshold, int8_t* __restrict__ xq,
+                   float* __restrict__ xout, float* __restrict__ sca, int32_t* __restrict__ nout) {
+    __shared__ float sh[4];
+    __shared__ int cnt;
+    const int m = blockIdx.x;
+    const bf16_t* xr = x + (int64_t)m * ldx;
+    if (threadIdx.x == 0) cnt = 0;
+    float mx = 0.f;
+    for (int k = threadIdx.x; k < K; k += 256) {
+        const float a = rhalf(bf2f(xr[k]));
+        if (!(threshold > 0.f && fabsf(a) >= threshold)) mx = fmaxf(mx, fabsf(a));
+    }
+    mx = block_max_256(mx, sh);
+    const float inv = mx > 0.f ? 127.0f / mx : 0.f;
+    int local = 0;
+    for (int k = threadIdx.x; k < K; k += 256) {
+        const float a = rhalf(bf2f(xr[k]));
+        const bool outlier = threshold > 0.f && fabsf(a) >= threshold;
+        xq[(int64_t)m * K + k] = outlier ? (int8_t)0 : (int8_t)rintf(a * inv);
+        xout[(int64_t)m * K + k] = outlier ? a : 0.f;
+        local += outlier ? 1 : 0;
+    }
+    if (local) atomicAdd(&cnt, local);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        sca[m] = mx;
+        nout[m] = cnt;
+    }
+}
+
+constexpr int kW8MaxSlabs = 8;  // K <= 8 * 4096
+constexpr int kW8U = 4;
+constexpr int kW8MaxRows = 16;
+
+template <bool DUAL, int J>
+__global__ void __launch_bounds__(512)
+w8_gemv_kernel(const uint4* __restrict__ CB, const uint4* __restrict__ CB2, const float* __restrict__ SCB,
+               const float* __restrict__ SCB2, const int8_t* __restrict__ xq, const float* __restrict__ xout,
+               const float* __restrict__ sca, const int32_t* __restrict__ nout, const bf16_t* __restrict__ bias,
+               const bf16_t* residual, int ldr, bf16_t* out, int ldo, int N, int K, int rows_per_wg, int epi, int nslabs) {
+    constexpr int NW = DUAL ? 2 : 1;
+    __shared__ int red[kW8MaxSlabs][kW8MaxRows * NW];
+    const int m = blockIdx.y;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int chunks = K >> 4;
+    const int c0 = (int)((int64_t)wave * chunks / nslabs), c1 = (int)((int64_t)(wave + 1) * chunks / nslabs);
+    int cidx[J];
+    int xr[J][4];
+#pragma unroll
+    for (int j = 0; j < J; ++j) {
+        const int c = c0 + j * 64 + lane;
+        const bool ok = c < c1;
+        cidx[j] = ok ? c : c1 - 1;
+        uint4 v = reinterpret_cast<const uint4*>(xq + (int64_t)m * K)[cidx[j]];
+        if (!ok) v = make_uint4(0, 0, 0, 0);
+        xr[j][0] = (int)v.x;
+        xr[j][1] = (int)v.y;
+        xr[j][2] = (int)v.z;
+        xr[j][3] = (int)v.w;
+    }
+    const int r_begin = blockIdx.x * rows_per_wg;
+    const int r_end = min(N, r_begin + rows_per_wg);
+    for (int r0 = r_begin; r0 < r_end; r0 += kW8U) {
+        uint4 w[NW][kW8U][J];
+#pragma unroll
+        for (int u = 0; u < kW8U; ++u) {
+            const int64_t row = min(r0 + u, N - 1);
+#pragma unroll
+            for (int j = 0; j < J; ++j) {
+                w[0][u][j] = CB[row * chunks + cidx[j]];
+                if (DUAL) w[1][u][j] = CB2[row * chunks + cidx[j]];
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < kW8U; ++u)
+#pragma unroll
+            for (int q = 0; q < NW; ++q) {
+                int p = 0;
+#pragma unroll
+                for (int j = 0; j < J; ++j) {
+                    p = __builtin_amdgcn_sdot4((int)w[q][u][j].x, xr[j][0], p, false);
+                    p = __builtin_amdgcn_sdot4((int)w[q][u][j].y, xr[j][1], p, false);
+                    p = __builtin_amdgcn_sdot4((int)w[q][u][j].z, xr[j][2], p, false);
+                    p = __builtin_amdgcn_sdot4((int)w[q][u][j].w, xr[j][3], p, false);
+                }
+#pragma unroll
+                for (int off = 32; off >= 1; off >>= 1) p += __shfl_xor(p, off, 64);
+                if (lane == 0) red[wave][(r0 - r_begin + u) * NW + q] = p;
+            }
+    }
+    __syncthreads();
+    const int nrows = r_end - r_begin;
+    if ((int)threadIdx.x < nrows) {
+        const int ur = threadIdx.x, col = r_begin + ur;
+        const float sa = sca[m];
+        const int no = nout[m];
+        float res[2] = {0.f, 0.f};
+#pragma unroll
+        for (int q = 0; q < NW; ++q) {
+            int c32 = 0;
+            for (int c = 0; c < nslabs; ++c) c32 += red[c][ur * NW + q];
+            const float scb = q ? SCB2[col] : SCB[col];
+            const float b = (bias != nullptr && q == 0) ? bf2f(bias[col]) : 0.f;
+            // separately rounded fp32 products and sum (no FMA), the order mm_dequant uses
+            float v = rhalf(__fadd_rn(__fmul_rn(__fmul_rn(__fmul_rn((float)c32, kMmDequant), sa), scb), b));
+            if (no > 0) {  // mixed-precision decomposition: scan the row for the outlier columns
+                const int8_t* wrow = reinterpret_cast<const int8_t*>(q ? CB2 : CB) + (int64_t)col * K;
+                float o = 0.f;
+                for (int k = 0; k < K; ++k) {
+                    const float a = xout[(int64_t)m * K + k];
+                    if (a != 0.f) o += a * rhalf(__fdiv_rn(__fmul_rn((float)wrow[k], scb), 127.0f));
+                }
+                v = rhalf(v + rhalf(o));
+            }
+            res[q] = v;
+        }
+        out[(int64_t)m * ldo + col] =
+            apply_epilogue(epi, res[0], res[1], nullptr, residual ? residual + (int64_t)m * ldr : nullptr, col);
+    }
+}
+
+template <int J>
+static int w8_launch(const void* CB, const void* CB2, const void* SCB, const void* SCB2, const void* xq, const void* xout,
+                     const void* sca, const void* nout, int M, const void* bias, const void* residual, int ldr, void* out,
+                     int ldo, int N, int K, int epi, int nslabs, hipStream_t st) {
+    const int R = N >= 16 * 2048 ? 16 : (N >= 8 * 1024 ? 8 : 4);
+    const dim3 grid((N + R - 1) / R, M), block(64 * nslabs);
+    if (epi == PARROT_EPI_SWIGLU)
+        return launch(K_W8_GEMV, w8_gemv_kernel<true, J>, grid, block, 0, st, (const uint4*)CB, (const uint4*)CB2,
+                      (const float*)SCB, (const float*)SCB2, (const int8_t*)xq, (const float*)xout, (const float*)sca,
+                      (const int32_t*)nout, (const bf16_t*)bias, (const bf16_t*)residual, ldr, (bf16_t*)out, ldo, N, K, R,
+                      epi, nslabs);
+    return launch(K_W8_GEMV, w8_gemv_kernel<false, J>, grid, block, 0, st, (const uint4*)CB, (const uint4*)CB2,
+                  (const float*)SCB, (const float*)SCB2, (const int8_t*)xq, (const float*)xout, (const float*)sca,
+                  (const int32_t*)nout, (const bf16_t*)bias, (const bf16_t*)residual, ldr, (bf16_t*)out, ldo, N, K, R, epi,
+                  nslabs);
+}
+
+}  // namespace parrot
+
+using namespace parrot;
+
+extern "C" {
+
+int parrot_w8_quantize_rows(const void* W_bf16, int N, int K, void* CB_int8, void* SCB_f32, void* stream) {
+    PARROT_REQUIRE(W_bf16 && CB_int8 && SCB_f32, "w8_quantize_rows: null pointer");
+    PARROT_REQUIRE(N >= 1 && K >= 1, "w8_quantize_rows: bad shape N=%d K=%d", N, K);
+    return launch(K_W8_QUANT_ROWS, w8_quantize_rows_kernel, dim3(N), dim3(256), 0, (hipStream_t)stream,
+                  (const bf16_t*)W_bf16, K, (int8_t*)CB_int8, (float*)SCB_f32);
+}
+
+int parrot_w8_prep_act(const void* x, int ldx, int M, int K, float threshold, void* xq, void* xout, void* sca, void* nout,
+                       void* stream) {
+    PARROT_REQUIRE(x && xq && xout && sca && nout, "w8_prep_act: null pointer");
+    PARROT_REQUIRE(M >= 1 && K >= 1 && ldx >= K, "w8_prep_act: bad shape M=%d K=%d ldx=%d", M, K, ldx);
+    return launch(K_W8_PREP_ACT, w8_prep_act_kernel, dim3(M), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, ldx, K,
+                  threshold, (int8_t*)xq, (float*)xout, (float*)sca, (int32_t*)nout);
+}
+
+// CB / SCB may be followed by a second weight for the SWIGLU epilogue: pass them concatenated as
+// CB = [CB1; CB2] is NOT assumed; the second weight is addressed as CB + N*K and SCB + N (fc_1 then fc_2 rows).
+int parrot_w8_gemv(const void* CB, const void* SCB, const void* xq, const void* xout, const void* sca, const void* nout,
+                   int M, const void* bias, const void* residual, int ldr, void* out, int ldo, int N, int K, int epilogue,
+                   void* stream) {
+    PARROT_REQUIRE(CB && SCB && xq && xout && sca && nout && out, "w8_gemv: null pointer");
+    PARROT_REQUIRE(M >= 1 && M <= 65535 && N >= 1 && K >= 1, "w8_gemv: bad shape M=%d N=%d K=%d", M, N, K);
+    PARROT_REQUIRE(epilogue >= PARROT_EPI_NONE && epilogue <= PARROT_EPI_SWIGLU, "w8_gemv: unknown epilogue %d", epilogue);
+    PARROT_REQUIRE((epilogue == PARROT_EPI_RESIDUAL) == (residual != nullptr), "w8_gemv: residual iff RESIDUAL epilogue");
+    PARROT_UNSUPPORTED(K % 16 == 0 && K <= 4096 * kW8MaxSlabs, "w8_gemv: K=%d must be a multiple of 16 and <= %d", K,
+                       4096 * kW8MaxSlabs);
+    PARROT_REQUIRE(aligned16(CB) && aligned16(xq), "w8_gemv: CB and xq must be 16-byte aligned");
+    PARROT_UNSUPPORTED(!(epilogue == PARROT_EPI_SWIGLU && bias), "w8_gemv: SWIGLU epilogue takes no bias");
+    const void* CB2 = nullptr;
+    const void* SCB2 = nullptr;
+    if (epilogue == PARROT_EPI_SWIGLU) {
+        CB2 = (const int8_t*)CB + (int64_t)N * K;
+        SCB2 = (const float*)SCB + N;
+    }
+    const int chunks = K / 16;
+    const int nslabs = (chunks + 255) / 256;
+    const int per_slab = (chunks + nslabs - 1) / nslabs;
+    const int jn = (per_slab + 63) / 64;
+    hipStream_t st = (hipStream_t)stream;
+    if (jn <= 1) return w8_launch<1>(CB, CB2, SCB, SCB2, xq, xout, sca, nout, M, bias, residual, ldr, out, ldo, N, K, epilogue, nslabs, st);
+    if (jn <= 2) return w8_launch<2>(CB, CB2, SCB, SCB2, xq, xout, sca, nout, M, bias, residual, ldr, out, ldo, N, K, epilogue, nslabs, st);
+    return w8_launch<4>(CB, CB2, SCB, SCB2, xq, xout, sca, nout, M, bias, residual, ldr, out, ldo, N, K, epilogue, nslabs, st);
+}
+
+}  // extern "C"

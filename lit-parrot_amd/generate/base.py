@@ -1,0 +1,158 @@
+"""The decode loop: ``generate()`` with the reference's signature (generate/base.py:92-159), hipGraph-captured.
+
+Reference loop per token: index_select the new token, ``model(x, max_seq_length, input_pos)``, divide by the
+temperature, optional top-k crop, softmax, multinomial, out-of-place ``index_copy`` into the token buffer and, when
+``eos_id`` is given, a host sync to compare (:131-157).  Here the loop state lives on the device:
+
+    tokens  int64[max_returned_tokens]   the prompt, then every sampled token
+    pos     int32[1]                     position of the row being decoded
+
+and one decode step — embedding of ``tokens[pos]``, every block, final norm, lm_head and, for greedy decoding, the
+arg-max that writes ``tokens[pos+1]`` and advances ``pos`` — is a fixed launch sequence captured ONCE per
+(model, max_seq_length) in a hipGraph and replayed per token.  Greedy decoding (``top_k == 1``, which is how the
+reference spells it: there is no argmax branch) never touches the host inside the loop unless ``eos_id`` is set.
+With ``top_k != 1`` the graph stops at the logits and the reference's own sampling ops (topk / where / softmax /
+multinomial, :139-144) run as torch ops on the device, so the same torch seed draws the same tokens.
+
+The prompt is prefilled in one multi-row pass (same kernels, M = T rows) that computes only the last row of lm_head
+(the reference computes all T rows and discards T-1 of them, :135-136).
+"""
+from typing import Dict, Optional, Tuple
+
+import torch
+
+from .. import ops
+from .._hip import ParrotHipError
+from ..model import GPT
+
+
+class DecodeSession:
+    """Static buffers + captured graph of the single-token step for one (model, max_seq_length, greedy) choice."""
+
+    def __init__(self, model: GPT, max_seq_length: int, max_tokens: int, greedy: bool, use_graph: bool = True) -> None:
+        self.model, self.S, self.greedy = model, max_seq_length, greedy
+        dev = model.transformer.wte.weight.device
+        if dev.type != "cuda":
+            raise ParrotHipError("generate() runs on the HIP device only: move the model to cuda (no CPU fallback)")
+        self.device = dev
+        self.tokens = torch.zeros((max_tokens + 1,), dtype=torch.int64, device=dev)
+        self.pos = torch.zeros((1,), dtype=torch.int32, device=dev)
+        self.ws = model.workspace(1, dev, 1)
+        self.graph: Optional[torch.cuda.CUDAGraph] = None
+        self.use_graph = use_graph
+        if model.rope_cache is None:
+            model.rope_cache = model.build_rope_cache(self.tokens)
+        if not model.kv_caches or model.kv_caches[0][0].size(2) != max_seq_length or model.kv_caches[0][0].size(0) != 1:
+            model.kv_caches = model.build_kv_caches(self.tokens.view(1, -1), max_seq_length, model.rope_cache[0].size(-1))
+        self.caches = [(k[0], v[0]) for k, v in model.kv_caches]
+
+    # one decode step = the launch sequence that gets captured
+    def _step(self) -> None:
+        logits = self.model.run_rows(self.ws, self.tokens, self.pos, self.pos, self.S, self.caches, self.model.rope_cache)
+        if self.greedy:
+            ops.argmax_advance(logits, self.tokens, self.pos)
+
+    def prefill(self, prompt: torch.Tensor) -> torch.Tensor:
+        """Run the T prompt rows, leave ``pos`` = T-1 and return the logits of the last prompt token."""
+        T = prompt.numel()
+        self.tokens[:T].copy_(prompt)
+        self.pos.zero_()
+        ws = self.model.workspace(T, self.device, 1)
+        logits = self.model.run_rows(ws, self.tokens, None, self.pos, self.S, self.caches, self.model.rope_cache)
+        self.pos.fill_(T - 1)
+        return logits
+
+    def capture(self) -> None:
+        if self.graph is not None or not self.use_graph:
+            return
+        # warm-up outside capture (lazy W4K repacks, workspace allocations), restoring the loop state afterwards
+        saved = (self.tokens.clone(), self.pos.clone(), [(k.clone(), v.clone()) for k, v in self.caches])
+        side = torch.cuda.Stream(device=self.device)
+        side.wait_stream(torch.cuda.current_stream(self.device))
+        with torch.cuda.stream(side):
+            self._step()
+        torch.cuda.current_stream(self.device).wait_stream(side)
+        torch.cuda.synchronize(self.device)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            self._step()
+        self.graph = graph
+        self.tokens.copy_(saved[0])
+        self.pos.copy_(saved[1])
+        for (k, v), (k0, v0) in zip(self.caches, saved[2]):
+            k.copy_(k0)
+            v.copy_(v0)
+
+    def step(self) -> torch.Tensor:
+        """Decode the token at ``pos``; returns the logits buffer (V,) of that step."""
+        if self.graph is not None:
+            self.graph.replay()
+        else:
+            self._step()
+        return self.ws.logits[0]
+
+
+def _session(model: GPT, max_seq_length: int, max_tokens: int, greedy: bool) -> DecodeSession:
+    cache: Dict[Tuple, DecodeSession] = model.__dict__.setdefault("_decode_sessions", {})
+    key = (max_seq_length, greedy)
+    sess = cache.get(key)
+    stale = (
+        sess is None
+        or sess.tokens.numel() < max_tokens + 1
+        or not model.kv_caches
+        or model.kv_caches[0][0].data_ptr() != sess.caches[0][0].data_ptr()
+    )
+    if stale:
+        cache.pop(key, None)
+        sess = DecodeSession(model, max_seq_length, max_tokens, greedy)
+        cache[key] = sess
+    return sess
+
+
+@torch.no_grad()
+def generate(
+    model: torch.nn.Module,
+    idx: torch.Tensor,
+    max_returned_tokens: int,
+    max_seq_length: int,
+    *,
+    temperature: float = 1.0,
+    top_k: Optional[int] = None,
+    eos_id: Optional[int] = None,
+) -> torch.Tensor:
+    """Continue the prompt ``idx`` (T,) up to ``max_returned_tokens`` tokens; same arguments and return value as the
+    reference (generate/base.py:93-159): a 1-D tensor holding the prompt followed by the generated tokens, cut after
+    ``eos_id`` when it is produced.  Call ``model.reset_cache()`` between prompts like the reference's ``main``."""
+    T = idx.size(0)
+    assert max_returned_tokens > T
+    if not isinstance(model, GPT):
+        raise ParrotHipError("generate() drives lit_parrot_amd.GPT models")
+    assert max_seq_length <= model.config.block_size
+    assert max_seq_length >= T, f"Cannot forward sequence of length {T}, max seq length is only {max_seq_length}"
+    dtype = idx.dtype
+    greedy = top_k == 1 and temperature > 0
+    sess = _session(model, max_seq_length, max_returned_tokens, greedy)
+    logits = sess.prefill(idx.to(device=sess.device, dtype=torch.int64))
+    sess.capture()
+
+    n_new = max_returned_tokens - T
+    for i in range(n_new):
+        # `logits` belong to the row at `pos` = T-1+i; sample tokens[T+i] from them and advance `pos`.
+        if greedy:
+            if i == 0:
+                ops.argmax_advance(logits, sess.tokens, sess.pos)  # later steps sample inside the captured graph
+        else:
+            lg = logits.view(-1) / temperature
+            if top_k is not None:
+                v, _ = torch.topk(lg, min(top_k, lg.size(-1)))
+                lg = torch.where(lg < v[[-1]], -float("Inf"), lg)
+            probs = torch.nn.functional.softmax(lg, dim=-1)
+            idx_next = torch.multinomial(probs, num_samples=1)
+            sess.tokens.index_copy_(0, (sess.pos + 1).to(torch.int64), idx_next)
+            sess.pos.add_(1)
+        if eos_id is not None and int(sess.tokens[T + i]) == eos_id:  # host sync, as in the reference (:156-157)
+            # the reference returns idx[:input_pos], which stops BEFORE the eos token despite its comment
+            return sess.tokens[: T + i].to(dtype).clone()
+        if i + 1 < n_new:
+            logits = sess.step()
+    return sess.tokens[:max_returned_tokens].to(dtype).clone()

@@ -1,0 +1,188 @@
+"""Tensor-level wrappers over the C ABI (``_hip.py``): shape checks, pointer extraction, dispatch per Linear class.
+
+Everything here enqueues HIP kernels on the current torch stream and returns immediately; nothing falls back to a
+torch implementation.  Activations are bf16 rows ``(M, features)`` of ONE sequence.
+"""
+from typing import Optional
+
+import torch
+
+from . import _hip
+from ._hip import EPI_GELU, EPI_NONE, EPI_RESIDUAL, EPI_SWIGLU, ParrotHipError, check, ptr, stream
+
+GEMV_MAX_ROWS = 8  # up to this many rows the weight-streaming GEMV kernels are used, above it the GEMM entry points
+
+
+def _rows(x: torch.Tensor, what: str) -> torch.Tensor:
+    if x.dtype != torch.bfloat16:
+        raise ParrotHipError(f"{what}: the HIP path computes in bf16 (got {x.dtype}); convert the model with .to(torch.bfloat16)")
+    if x.dim() != 2 or x.stride(1) != 1:
+        raise ParrotHipError(f"{what}: expected contiguous rows (M, features), got shape {tuple(x.shape)} strides {x.stride()}")
+    return x
+
+
+def _opt_vec(t: Optional[torch.Tensor], n: int, what: str) -> Optional[torch.Tensor]:
+    if t is None:
+        return None
+    if t.dtype != torch.bfloat16 or t.numel() != n or not t.is_contiguous():
+        raise ParrotHipError(f"{what}: expected a contiguous bf16 vector of {n} elements")
+    return t
+
+
+# ------------------------------------------------------------------------------------------------ norms
+def rmsnorm(x: torch.Tensor, weight: torch.Tensor, eps: float, out: torch.Tensor) -> torch.Tensor:
+    _rows(x, "rmsnorm"), _rows(out, "rmsnorm")
+    M, d = x.shape
+    check(_hip.load().parrot_rmsnorm(ptr(x), x.stride(0), ptr(_opt_vec(weight, d, "rmsnorm weight")), ptr(out),
+                                     out.stride(0), M, d, float(eps), stream()), "parrot_rmsnorm")
+    return out
+
+
+def layernorm(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor], eps: float,
+              out: torch.Tensor) -> torch.Tensor:
+    _rows(x, "layernorm"), _rows(out, "layernorm")
+    M, d = x.shape
+    check(_hip.load().parrot_layernorm(ptr(x), x.stride(0), ptr(_opt_vec(weight, d, "layernorm weight")),
+                                       ptr(_opt_vec(bias, d, "layernorm bias")), ptr(out), out.stride(0), M, d,
+                                       float(eps), stream()), "parrot_layernorm")
+    return out
+
+
+# ------------------------------------------------------------------------------------------------ linears
+def bf16_linear(weight: torch.Tensor, x: torch.Tensor, out: torch.Tensor, *, bias=None, epilogue=EPI_NONE,
+                residual=None, weight2=None) -> torch.Tensor:
+    _rows(x, "bf16_linear"), _rows(out, "bf16_linear")
+    N, K = weight.shape
+    if weight.dtype != torch.bfloat16 or not weight.is_contiguous():
+        raise ParrotHipError("bf16_linear: weight must be contiguous bf16 (out_features, in_features)")
+    M = x.shape[0]
+    lib = _hip.load()
+    fn = lib.parrot_bf16_gemv if M <= GEMV_MAX_ROWS else lib.parrot_bf16_gemm
+    check(fn(ptr(weight), ptr(weight2), ptr(x), x.stride(0), M, ptr(_opt_vec(bias, N, "bias")),
+             ptr(residual), residual.stride(0) if residual is not None else 0, ptr(out), out.stride(0), N, K,
+             epilogue, stream()), "parrot_bf16_gemv/gemm")
+    return out
+
+
+def w4_packed_bytes(N: int, K: int, group: int) -> int:
+    n = _hip.load().parrot_w4_packed_bytes(N, K, group)
+    if n < 0:
+        raise ParrotHipError(f"parrot_w4_packed_bytes({N}, {K}, {group}) failed: {_hip.last_error()}")
+    return n
+
+
+def w4_repack(quant_weight: torch.Tensor, scales: torch.Tensor, zeros: torch.Tensor, N: int, K: int, group: int,
+              packed: torch.Tensor, direction: int) -> None:
+    """direction 0: reference buffers -> W4K ``packed``; 1: the inverse (writes the reference buffers)."""
+    if quant_weight.dtype != torch.uint8 or quant_weight.shape != (N, K // 2) or quant_weight.stride() != (1, N):
+        raise ParrotHipError("w4_repack: quant_weight must be uint8 (N, K/2) with strides (1, N) (quantize/gptq.py:216-222)")
+    for t, nm in ((scales, "scales"), (zeros, "zeros")):
+        if t.dtype != torch.bfloat16 or not t.is_contiguous() or t.shape[0] != N:
+            raise ParrotHipError(f"w4_repack: {nm} must be contiguous bf16 (N, groups)")
+    if packed.dtype != torch.uint8 or packed.numel() != w4_packed_bytes(N, K, group):
+        raise ParrotHipError("w4_repack: packed buffer has the wrong size")
+    check(_hip.load().parrot_w4_repack(ptr(quant_weight), ptr(scales), ptr(zeros), N, K, group, ptr(packed), direction,
+                                       stream()), "parrot_w4_repack")
+
+
+def w4_linear(packed: torch.Tensor, N: int, K: int, group: int, x: torch.Tensor, out: torch.Tensor, *, bias=None,
+              epilogue=EPI_NONE, residual=None, packed2=None) -> torch.Tensor:
+    _rows(x, "w4_linear"), _rows(out, "w4_linear")
+    M = x.shape[0]
+    if x.shape[1] != K or out.shape[1] != N:
+        raise ParrotHipError(f"w4_linear: x {tuple(x.shape)} / out {tuple(out.shape)} do not match N={N} K={K}")
+    lib = _hip.load()
+    fn = lib.parrot_w4_gemv if M <= GEMV_MAX_ROWS else lib.parrot_w4_gemm
+    check(fn(ptr(packed), ptr(packed2), ptr(x), x.stride(0), M, ptr(_opt_vec(bias, N, "bias")), ptr(residual),
+             residual.stride(0) if residual is not None else 0, ptr(out), out.stride(0), N, K, group, epilogue,
+             stream()), "parrot_w4_gemv/gemm")
+    return out
+
+
+def w8_quantize_rows(weight: torch.Tensor, CB: torch.Tensor, SCB: torch.Tensor) -> None:
+    N, K = weight.shape
+    if weight.dtype != torch.bfloat16 or not weight.is_contiguous():
+        raise ParrotHipError("w8_quantize_rows: weight must be contiguous bf16")
+    check(_hip.load().parrot_w8_quantize_rows(ptr(weight), N, K, ptr(CB), ptr(SCB), stream()), "parrot_w8_quantize_rows")
+
+
+class W8Act:
+    """Quantised activation rows of one LLM.int8 Linear input (buffers are reused across calls)."""
+
+    def __init__(self, M: int, K: int, device) -> None:
+        self.M, self.K = M, K
+        self.xq = torch.empty((M, K), dtype=torch.int8, device=device)
+        self.xout = torch.empty((M, K), dtype=torch.float32, device=device)
+        self.sca = torch.empty((M,), dtype=torch.float32, device=device)
+        self.nout = torch.empty((M,), dtype=torch.int32, device=device)
+
+
+def w8_prep_act(x: torch.Tensor, threshold: float, act: W8Act) -> W8Act:
+    _rows(x, "w8_prep_act")
+    M, K = x.shape
+    assert (M, K) == (act.M, act.K)
+    check(_hip.load().parrot_w8_prep_act(ptr(x), x.stride(0), M, K, float(threshold), ptr(act.xq), ptr(act.xout),
+                                         ptr(act.sca), ptr(act.nout), stream()), "parrot_w8_prep_act")
+    return act
+
+
+def w8_linear(CB: torch.Tensor, SCB: torch.Tensor, N: int, K: int, act: W8Act, out: torch.Tensor, *, bias=None,
+              epilogue=EPI_NONE, residual=None) -> torch.Tensor:
+    _rows(out, "w8_linear")
+    check(_hip.load().parrot_w8_gemv(ptr(CB), ptr(SCB), ptr(act.xq), ptr(act.xout), ptr(act.sca), ptr(act.nout), act.M,
+                                     ptr(_opt_vec(bias, N, "bias")), ptr(residual),
+                                     residual.stride(0) if residual is not None else 0, ptr(out), out.stride(0), N, K,
+                                     epilogue, stream()), "parrot_w8_gemv")
+    return out
+
+
+# ------------------------------------------------------------------------------------------------ attention
+def rope_kvappend(qkv: torch.Tensor, cos: torch.Tensor, sin: torch.Tensor, n_elem: int, pos: torch.Tensor,
+                  n_groups: int, q_per_kv: int, hs: int, S: int, q_out: torch.Tensor, k_cache: torch.Tensor,
+                  v_cache: torch.Tensor, rope_local: bool = False) -> None:
+    _rows(qkv, "rope_kvappend")
+    if cos.dtype != torch.float16 or sin.dtype != torch.float16 or not cos.is_contiguous() or not sin.is_contiguous():
+        raise ParrotHipError("rope_kvappend: the RoPE tables must be contiguous fp16 (lit_gpt/model.py:325-326)")
+    if pos.dtype != torch.int32 or k_cache.dtype != torch.bfloat16 or v_cache.dtype != torch.bfloat16:
+        raise ParrotHipError("rope_kvappend: pos must be int32 and the caches bf16")
+    if k_cache.numel() != n_groups * S * hs or v_cache.numel() != n_groups * S * hs or not k_cache.is_contiguous():
+        raise ParrotHipError("rope_kvappend: cache shape must be (n_groups, S, hs) contiguous")
+    check(_hip.load().parrot_qkv_rope_kvappend(ptr(qkv), qkv.stride(0), qkv.shape[0], ptr(cos), ptr(sin), n_elem,
+                                               int(rope_local), ptr(pos), n_groups, q_per_kv, hs, S, ptr(q_out), ptr(k_cache),
+                                               ptr(v_cache), stream()), "parrot_qkv_rope_kvappend")
+
+
+def attn_nsplit(n_groups: int, S: int) -> int:
+    """Sequence splits of the decode-attention kernel: enough workgroups to cover the chip, >= 64 keys each."""
+    return max(1, min(S // 64, max(1, 512 // n_groups), 32))
+
+
+def attn_workspace(M: int, n_head: int, hs: int, nsplit: int, device) -> torch.Tensor:
+    n = _hip.load().parrot_attn_workspace_floats(M, n_head, hs, nsplit)
+    return torch.empty((max(int(n), 1),), dtype=torch.float32, device=device)
+
+
+def attn_decode(q: torch.Tensor, pos: torch.Tensor, k_cache: torch.Tensor, v_cache: torch.Tensor, n_groups: int,
+                q_per_kv: int, hs: int, S: int, nsplit: int, workspace: torch.Tensor, y: torch.Tensor) -> torch.Tensor:
+    _rows(y, "attn_decode")
+    M = y.shape[0]
+    check(_hip.load().parrot_attn_decode(ptr(q), M, ptr(pos), ptr(k_cache), ptr(v_cache), n_groups, q_per_kv, hs, S,
+                                         nsplit, ptr(workspace), ptr(y), y.stride(0), stream()), "parrot_attn_decode")
+    return y
+
+
+# ------------------------------------------------------------------------------------------------ step glue
+def embedding(wte: torch.Tensor, tokens: torch.Tensor, pos: Optional[torch.Tensor], M: int, out: torch.Tensor) -> torch.Tensor:
+    _rows(out, "embedding")
+    if wte.dtype != torch.bfloat16 or not wte.is_contiguous() or tokens.dtype != torch.int64:
+        raise ParrotHipError("embedding: wte must be contiguous bf16 and tokens int64")
+    check(_hip.load().parrot_embedding(ptr(wte), wte.shape[1], ptr(tokens), ptr(pos), M, ptr(out), out.stride(0),
+                                       stream()), "parrot_embedding")
+    return out
+
+
+def argmax_advance(logits: torch.Tensor, tokens: torch.Tensor, pos: torch.Tensor) -> None:
+    if logits.dtype != torch.bfloat16 or tokens.dtype != torch.int64 or pos.dtype != torch.int32:
+        raise ParrotHipError("argmax_advance: logits bf16, tokens int64, pos int32 expected")
+    check(_hip.load().parrot_argmax_advance(ptr(logits), logits.numel(), ptr(tokens), ptr(pos), stream()),
+          "parrot_argmax_advance")

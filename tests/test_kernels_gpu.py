@@ -1,0 +1,356 @@
+"""Every C-ABI entry point against the CPU oracle on seeded inputs (runs on the MI355X box: ``-m gpu``).
+
+Expected values are computed on the CPU in float64 from exactly the same bf16/int inputs, with the reference's
+rounding points (bf16 after the Linear, after the activation, after the residual add ...).  The GPU accumulates in
+fp32 in a different order, so a result may land on the neighbouring bf16 value: the bar is <= 1 bf16 ulp unless a
+test says otherwise; integer / byte / index work is compared exactly.
+"""
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from helpers import assert_bf16_close, rbf
+
+pytestmark = pytest.mark.gpu
+
+from lit_parrot_amd import ops  # noqa: E402
+from lit_parrot_amd._hip import EPI_GELU, EPI_NONE, EPI_RESIDUAL, EPI_SWIGLU, ParrotHipError  # noqa: E402
+from lit_parrot_amd.quantize.gptq import ColBlockQuantizedLinear  # noqa: E402
+from oracle import int4 as o4  # noqa: E402
+from oracle import int8 as o8  # noqa: E402
+from oracle import model as om  # noqa: E402
+
+DEV = torch.device("cuda", 0)
+BF = torch.bfloat16
+
+
+def gen(seed):
+    return torch.Generator().manual_seed(seed)
+
+
+def expected_epilogue(acc, acc2, bias, residual, epi):
+    """acc: float64 dot products.  Mirrors parrot_common.h::apply_epilogue / the reference's bf16 rounding points."""
+    v = acc + (bias.double() if bias is not None else 0)
+    v = rbf(v)
+    if epi == EPI_RESIDUAL:
+        v = residual.double() + v
+    elif epi == EPI_GELU:
+        v = F.gelu(v)
+    elif epi == EPI_SWIGLU:
+        v = rbf(F.silu(v)) * rbf(acc2)
+    return v
+
+
+# ------------------------------------------------------------------------------------------------ int4
+W4_SHAPES = [  # N, K, group
+    (64, 256, 128), (48, 256, -1), (48, 256, 64), (40, 352, 128), (16, 64, 32), (32, 768, 128),
+    (256, 4096, 128), (128, 11008, 128), (24, 8192, 128), (8, 32768, 128), (100, 4096, -1), (36, 2048, 256),
+]
+
+
+def make_w4(N, K, group, seed):
+    g = gen(seed)
+    w = (torch.randn(N, K, generator=g) * 0.02).to(BF)
+    qw, s, z = o4.rtn_quantize(w, group, BF)
+    tc = K if group == -1 else group
+    return qw, s, z, tc, o4.get_weight(qw, s.float(), z.float(), tc, torch.float32).double()  # exact (q-z)*s
+
+
+def w4_module(qw, s, z, N, K, group, bias=None):
+    lin = ColBlockQuantizedLinear(K, N, bias is not None, bits=4, tile_cols=group)
+    lin.quant_weight.copy_(qw)
+    lin.scales = s.clone()
+    lin.zeros = z.clone()
+    if bias is not None:
+        lin.bias = bias.clone()
+    return lin.to(DEV)
+
+
+@pytest.mark.parametrize("N,K,group", W4_SHAPES)
+def test_w4_repack_round_trip_is_exact(N, K, group):
+    qw, s, z, tc, _ = make_w4(N, K, group, 1)
+    lin = w4_module(qw, s, z, N, K, group)
+    packed = lin.packed()
+    qw2 = torch.zeros_like(lin.quant_weight)
+    assert qw2.stride() == (1, N)
+    s2, z2 = torch.zeros_like(lin.scales), torch.zeros_like(lin.zeros)
+    ops.w4_repack(qw2, s2, z2, N, K, tc, packed, 1)
+    assert torch.equal(qw2.cpu(), qw) and torch.equal(s2.cpu(), s) and torch.equal(z2.cpu(), z)
+
+
+@pytest.mark.parametrize("N,K,group", W4_SHAPES)
+@pytest.mark.parametrize("M", [1, 3])
+def test_w4_gemv_matches_oracle(N, K, group, M):
+    qw, s, z, tc, Wd = make_w4(N, K, group, 2)
+    g = gen(3)
+    x = torch.randn(M, K, generator=g).to(BF)
+    bias = (torch.randn(N, generator=g) * 0.1).to(BF)
+    lin = w4_module(qw, s, z, N, K, group, bias)
+    out = torch.empty((M, N), dtype=BF, device=DEV)
+    lin.hip_linear(x.to(DEV), out)
+    want = expected_epilogue(x.double() @ Wd.t(), None, bias, None, EPI_NONE)
+    assert_bf16_close(out, want, ulps=1, atol=2e-3, what=f"w4_gemv N={N} K={K} g={group} M={M}")
+    # the reference's definition (bf16 get_weight + F.linear, gptq.py:263-264) within the int4 bound of north_star
+    ref = F.linear(x, o4.get_weight(qw, s, z, tc, BF), bias)
+    assert float((out.cpu().float() - ref.float()).abs().max()) <= 1e-2 * max(1.0, float(ref.float().abs().max()))
+
+
+@pytest.mark.parametrize("M", [1, 2, 4, 5, 9])
+@pytest.mark.parametrize("epi", [EPI_NONE, EPI_RESIDUAL, EPI_GELU, EPI_SWIGLU])
+def test_w4_epilogues_and_row_counts(M, epi):
+    N, K, group = 96, 512, 128
+    qw, s, z, tc, Wd = make_w4(N, K, group, 4)
+    qw2, s2, z2, _, Wd2 = make_w4(N, K, group, 5)
+    g = gen(6)
+    x = torch.randn(M, K, generator=g).to(BF)
+    res = torch.randn(M, N, generator=g).to(BF)
+    bias = None if epi == EPI_SWIGLU else (torch.randn(N, generator=g) * 0.1).to(BF)
+    lin, lin2 = w4_module(qw, s, z, N, K, group, bias), w4_module(qw2, s2, z2, N, K, group)
+    out = torch.empty((M, N), dtype=BF, device=DEV)
+    lin.hip_linear(x.to(DEV), out, epilogue=epi, residual=res.to(DEV) if epi == EPI_RESIDUAL else None,
+                   partner=lin2 if epi == EPI_SWIGLU else None)
+    want = expected_epilogue(x.double() @ Wd.t(), x.double() @ Wd2.t(), bias, res, epi)
+    assert_bf16_close(out, want, ulps=1, atol=2e-3, what=f"w4 epilogue {epi} M={M}")
+
+
+def test_w4_residual_in_place_and_linearity():
+    """x <- x + W y in place (the decode step does this), and the kernel is linear in x up to bf16 rounding."""
+    N, K, group = 128, 4096, 128
+    qw, s, z, tc, Wd = make_w4(N, K, group, 7)
+    lin = w4_module(qw, s, z, N, K, group)
+    g = gen(8)
+    y = torch.randn(1, K, generator=g).to(BF)
+    xres = torch.randn(1, N, generator=g).to(BF)
+    buf = xres.to(DEV).clone()
+    lin.hip_linear(y.to(DEV), buf, epilogue=EPI_RESIDUAL, residual=buf)
+    assert_bf16_close(buf, xres.double() + rbf(y.double() @ Wd.t()), ulps=1, atol=2e-3, what="in-place residual")
+    # scaling x by 2 (exact in bf16) scales the output by exactly 2
+    o1, o2 = torch.empty((1, N), dtype=BF, device=DEV), torch.empty((1, N), dtype=BF, device=DEV)
+    lin.hip_linear(y.to(DEV), o1)
+    lin.hip_linear((y * 2).to(DEV), o2)
+    assert torch.equal(o2, o1 * 2)
+
+
+def test_w4_module_forward_shape_and_bad_inputs():
+    N, K, group = 64, 256, 128
+    qw, s, z, tc, Wd = make_w4(N, K, group, 9)
+    lin = w4_module(qw, s, z, N, K, group)
+    x = torch.randn(2, 3, K, generator=gen(1)).to(BF)
+    out = lin(x.to(DEV))
+    assert out.shape == (2, 3, N) and out.dtype == BF
+    assert_bf16_close(out.view(6, N), rbf(x.view(6, K).double() @ Wd.t()), ulps=1, atol=2e-3, what="module forward")
+    with pytest.raises(ParrotHipError):
+        lin(x.to(DEV).float())  # fp32 activations: not built
+
+
+# ------------------------------------------------------------------------------------------------ dense bf16
+@pytest.mark.parametrize("N,K", [(64, 128), (100, 768), (64, 4096), (32, 16384), (16, 3072), (8, 32768), (40, 352)])
+@pytest.mark.parametrize("M", [1, 2, 3])
+def test_bf16_gemv_matches_oracle(N, K, M):
+    g = gen(10)
+    W = (torch.randn(N, K, generator=g) * 0.02).to(BF)
+    x = torch.randn(M, K, generator=g).to(BF)
+    bias = (torch.randn(N, generator=g) * 0.1).to(BF)
+    out = torch.empty((M, N), dtype=BF, device=DEV)
+    ops.bf16_linear(W.to(DEV), x.to(DEV), out, bias=bias.to(DEV))
+    assert_bf16_close(out, rbf(x.double() @ W.double().t() + bias.double()), ulps=1, atol=1e-3, what=f"bf16 gemv {N}x{K}")
+    # and torch's own bf16 Linear on the CPU (what the reference runs)
+    assert float((out.cpu().float() - F.linear(x, W, bias).float()).abs().max()) <= 1e-2
+
+
+@pytest.mark.parametrize("epi", [EPI_RESIDUAL, EPI_GELU, EPI_SWIGLU])
+def test_bf16_epilogues(epi):
+    N, K, M = 72, 1024, 2
+    g = gen(11)
+    W, W2 = ((torch.randn(N, K, generator=g) * 0.05).to(BF) for _ in range(2))
+    x, res = torch.randn(M, K, generator=g).to(BF), torch.randn(M, N, generator=g).to(BF)
+    out = torch.empty((M, N), dtype=BF, device=DEV)
+    ops.bf16_linear(W.to(DEV), x.to(DEV), out, epilogue=epi, residual=res.to(DEV) if epi == EPI_RESIDUAL else None,
+                    weight2=W2.to(DEV) if epi == EPI_SWIGLU else None)
+    want = expected_epilogue(x.double() @ W.double().t(), x.double() @ W2.double().t(), None, res, epi)
+    assert_bf16_close(out, want, ulps=1, atol=1e-3, what=f"bf16 epilogue {epi}")
+
+
+# ------------------------------------------------------------------------------------------------ LLM.int8
+def test_w8_weight_quantisation_is_exact():
+    g = gen(12)
+    W = (torch.randn(50, 352, generator=g) * 0.02).to(BF)
+    W[7] = 0
+    CB = torch.empty((50, 352), dtype=torch.int8, device=DEV)
+    SCB = torch.empty((50,), dtype=torch.float32, device=DEV)
+    ops.w8_quantize_rows(W.to(DEV), CB, SCB)
+    cb, scb = o8.quantize_weight_rows(W)
+    assert torch.equal(CB.cpu(), cb) and torch.equal(SCB.cpu(), scb)
+
+
+@pytest.mark.parametrize("N,K", [(64, 256), (96, 4096), (40, 352), (16, 11008)])
+@pytest.mark.parametrize("outliers", [False, True])
+@pytest.mark.parametrize("M", [1, 3])
+def test_w8_linear_matches_oracle(N, K, outliers, M):
+    g = gen(13)
+    W = (torch.randn(N, K, generator=g) * 0.02).to(BF)
+    x = torch.randn(M, K, generator=g).to(BF)
+    if outliers:  # force the mixed-precision decomposition: |x| >= 6 in a few columns
+        x[0, 3], x[0, K - 1], x[M - 1, 17] = 9.5, -7.25, 6.0
+    bias = (torch.randn(N, generator=g) * 0.1).to(BF)
+    cb, scb = o8.quantize_weight_rows(W)
+    act = ops.w8_prep_act(x.to(DEV), 6.0, ops.W8Act(M, K, DEV))
+    ca, sca, xout = o8.quantize_act_rows(x, 6.0)
+    assert torch.equal(act.xq.cpu(), ca) and torch.equal(act.sca.cpu(), sca) and torch.equal(act.xout.cpu(), xout)
+    assert act.nout.cpu().tolist() == (xout != 0).sum(dim=1).tolist()
+    out = torch.empty((M, N), dtype=BF, device=DEV)
+    ops.w8_linear(cb.to(DEV), scb.to(DEV), N, K, act, out, bias=bias.to(DEV))
+    want = o8.linear(x, cb, scb, bias, 6.0)
+    # integer accumulate is exact; the fp16 roundings make it bit-exact up to fp32 summation order in the outlier part
+    assert_bf16_close(out, want.float(), ulps=1 if outliers else 0, atol=0.0, what=f"w8 {N}x{K} outliers={outliers}")
+
+
+# ------------------------------------------------------------------------------------------------ norms
+@pytest.mark.parametrize("d", [128, 768, 4096, 8192])
+def test_rmsnorm_matches_reference_choreography(d):
+    g = gen(14)
+    x = (torch.randn(3, d, generator=g) * 2).to(BF)
+    w = (1 + 0.1 * torch.randn(d, generator=g)).to(BF)
+    out = torch.empty((3, d), dtype=BF, device=DEV)
+    ops.rmsnorm(x.to(DEV), w.to(DEV), 1e-5, out)
+    assert_bf16_close(out, om.rms_norm(x, w, 1e-5).float(), ulps=1, what="rmsnorm")  # summation order only
+    assert float((out.cpu() == om.rms_norm(x, w, 1e-5)).float().mean()) > 0.98
+
+
+@pytest.mark.parametrize("d", [128, 768, 4096, 8192])
+def test_layernorm_matches_torch(d):
+    g = gen(15)
+    x = (torch.randn(3, d, generator=g) * 2 + 0.3).to(BF)
+    w, b = (1 + 0.1 * torch.randn(d, generator=g)).to(BF), (0.1 * torch.randn(d, generator=g)).to(BF)
+    out = torch.empty((3, d), dtype=BF, device=DEV)
+    ops.layernorm(x.to(DEV), w.to(DEV), b.to(DEV), 1e-5, out)
+    want = F.layer_norm(x.double(), (d,), w.double(), b.double(), 1e-5)
+    assert_bf16_close(out, want, ulps=1, atol=1e-3, what="layernorm")
+    assert float((out.cpu().float() - F.layer_norm(x, (d,), w, b, 1e-5).float()).abs().max()) <= 2 ** -6
+
+
+# ------------------------------------------------------------------------------------------------ attention
+ATTN_SHAPES = [  # n_groups, q_per_kv, hs, n_elem
+    (4, 1, 32, 8), (2, 1, 64, 64), (2, 2, 64, 64), (2, 1, 128, 128), (2, 4, 32, 32), (1, 4, 32, 32), (2, 16, 64, 64), (3, 1, 128, 32),
+]
+
+
+def ref_attention(qkv, cos, sin, pos0, n_groups, q_per_kv, hs, n_elem, S, kc, vc):
+    """The reference's split / rope / cache append / SDPA (model.py:208-247) in float64 on bf16 inputs; kc, vc are the
+    (n_groups, S, hs) caches BEFORE the call (updated in place, slot = position)."""
+    T = qkv.shape[0]
+    v5 = qkv.view(T, n_groups, q_per_kv + 2, hs)
+    q, k, v = v5[:, :, :q_per_kv], v5[:, :, q_per_kv], v5[:, :, q_per_kv + 1]
+    pos = torch.arange(pos0, pos0 + T)
+    c, s = cos.index_select(0, pos), sin.index_select(0, pos)  # (T, n_elem) fp16
+    qr = torch.cat((om.apply_rope(q[..., :n_elem].permute(1, 2, 0, 3), c, s), q[..., n_elem:].permute(1, 2, 0, 3)), dim=-1)  # (G, qpk, T, hs)
+    kr = torch.cat((om.apply_rope(k[..., :n_elem].permute(1, 0, 2), c, s), k[..., n_elem:].permute(1, 0, 2)), dim=-1)  # (G, T, hs)
+    kc[:, pos] = kr
+    vc[:, pos] = v.permute(1, 0, 2)
+    y = torch.empty((T, n_groups * q_per_kv * hs), dtype=torch.float64)
+    for t in range(T):
+        n_valid = pos0 + t + 1
+        K_, V_ = kc[:, :n_valid].double(), vc[:, :n_valid].double()
+        att = torch.einsum("gqd,gsd->gqs", qr[:, :, t].double(), K_) / math.sqrt(hs)
+        y[t] = torch.einsum("gqs,gsd->gqd", att.softmax(-1), V_).reshape(-1)
+    return qr, y
+
+
+@pytest.mark.parametrize("n_groups,q_per_kv,hs,n_elem", ATTN_SHAPES)
+@pytest.mark.parametrize("S,nsplit", [(16, 1), (96, 1), (96, 3), (700, 8)])
+def test_rope_append_and_attention(n_groups, q_per_kv, hs, n_elem, S, nsplit):
+    g = gen(16)
+    n_head = n_groups * q_per_kv
+    width = n_groups * (q_per_kv + 2) * hs
+    cos, sin = om.rope_tables(1024, n_elem, BF, math_dtype=BF)
+    T = min(9, S)
+    kc = torch.zeros((n_groups, S, hs), dtype=BF)
+    vc = torch.zeros((n_groups, S, hs), dtype=BF)
+    kc_d, vc_d = kc.to(DEV), vc.to(DEV)
+    q_d = torch.empty((T, n_head * hs), dtype=BF, device=DEV)
+    y_d = torch.empty((T, n_head * hs), dtype=BF, device=DEV)
+    ws = ops.attn_workspace(T, n_head, hs, nsplit, DEV)
+    cos_d, sin_d = cos.to(DEV), sin.to(DEV)
+    pos0 = 0
+    for step, rows in enumerate([T, 1, 1, 1]):  # a prefill of T rows, then single-token steps
+        if pos0 + rows > S:
+            break
+        qkv = torch.randn(rows, width, generator=g).to(BF)
+        qr, want = ref_attention(qkv, cos, sin, pos0, n_groups, q_per_kv, hs, n_elem, S, kc, vc)
+        pos_d = torch.tensor([pos0], dtype=torch.int32, device=DEV)
+        ops.rope_kvappend(qkv.to(DEV), cos_d, sin_d, n_elem, pos_d, n_groups, q_per_kv, hs, S, q_d[:rows], kc_d, vc_d)
+        # roped q and the cache contents are bit-exact (same fp32 ops, no FMA)
+        assert torch.equal(q_d[:rows].cpu().view(rows, n_groups, q_per_kv, hs), qr.permute(2, 0, 1, 3))
+        assert torch.equal(kc_d.cpu(), kc) and torch.equal(vc_d.cpu(), vc)
+        ops.attn_decode(q_d[:rows], pos_d, kc_d, vc_d, n_groups, q_per_kv, hs, S, nsplit, ws, y_d[:rows])
+        assert_bf16_close(y_d[:rows], want, ulps=1, atol=2e-3, what=f"attention step {step}")
+        pos0 += rows
+
+
+def test_attention_ring_window_equals_rolled_cache():
+    """pos >= S: slot = pos % S replaces the oldest key — the reference's roll-left + write-last (model.py:238-245)."""
+    n_groups, q_per_kv, hs, n_elem, S = 2, 2, 64, 64, 10
+    g = gen(17)
+    cos, sin = om.rope_tables(64, n_elem, BF, math_dtype=BF)
+    kc_d = torch.zeros((n_groups, S, hs), dtype=BF, device=DEV)
+    vc_d = torch.zeros_like(kc_d)
+    n_head, width = n_groups * q_per_kv, n_groups * (q_per_kv + 2) * hs
+    q_d = torch.empty((1, n_head * hs), dtype=BF, device=DEV)
+    y_d = torch.empty_like(q_d)
+    ks, vs = [], []
+    for pos in range(25):
+        qkv = torch.randn(1, width, generator=g).to(BF)
+        # oracle: keep the last S (roped) keys/values explicitly
+        kfull = torch.zeros((n_groups, pos + 1, hs), dtype=BF)
+        vfull = torch.zeros_like(kfull)
+        qr, _ = ref_attention(qkv, cos, sin, pos, n_groups, q_per_kv, hs, n_elem, pos + 1, kfull, vfull)
+        ks.append(kfull[:, pos]); vs.append(vfull[:, pos])
+        K_ = torch.stack(ks[-S:], 1).double(); V_ = torch.stack(vs[-S:], 1).double()
+        att = torch.einsum("gqd,gsd->gqs", qr[:, :, 0].double(), K_) / math.sqrt(hs)
+        want = torch.einsum("gqs,gsd->gqd", att.softmax(-1), V_).reshape(1, -1)
+        pos_d = torch.tensor([pos], dtype=torch.int32, device=DEV)
+        ops.rope_kvappend(qkv.to(DEV), cos.to(DEV), sin.to(DEV), n_elem, pos_d, n_groups, q_per_kv, hs, S, q_d, kc_d, vc_d)
+        ops.attn_decode(q_d, pos_d, kc_d, vc_d, n_groups, q_per_kv, hs, S, 1, None, y_d)
+        assert_bf16_close(y_d, want, ulps=1, atol=2e-3, what=f"ring pos {pos}")
+
+
+# ------------------------------------------------------------------------------------------------ step glue
+def test_embedding_and_argmax_advance():
+    g = gen(18)
+    wte = torch.randn(300, 128, generator=g).to(BF)
+    tokens = torch.tensor([5, 299, 0, 17, 42, 0, 0, 0], dtype=torch.int64)
+    out = torch.empty((3, 128), dtype=BF, device=DEV)
+    ops.embedding(wte.to(DEV), tokens.to(DEV), None, 3, out)
+    assert torch.equal(out.cpu(), wte[tokens[:3]])
+    pos = torch.tensor([3], dtype=torch.int32, device=DEV)
+    ops.embedding(wte.to(DEV), tokens.to(DEV), pos, 2, out[:2])
+    assert torch.equal(out[:2].cpu(), wte[tokens[3:5]])
+    # argmax: unique maximum, then a tie (lowest index wins), then a NaN that must not win
+    tok_d = tokens.to(DEV)
+    for V in (300, 32000, 50304):
+        logits = torch.randn(V, generator=g).to(BF)
+        logits[V - 7] = 9.0
+        pos = torch.tensor([4], dtype=torch.int32, device=DEV)
+        ops.argmax_advance(logits.to(DEV), tok_d, pos)
+        assert int(pos) == 5 and int(tok_d[5]) == V - 7
+        logits[11] = 9.0
+        logits[3] = float("nan")
+        ops.argmax_advance(logits.to(DEV), tok_d, pos)
+        assert int(pos) == 6 and int(tok_d[6]) == 11
+        tok_d[5:7] = 0
+
+
+def test_profiling_sink_reports_kernels():
+    from lit_parrot_amd import _hip
+
+    x = torch.randn(2, 256).to(BF).to(DEV)
+    w = torch.ones(256, dtype=BF, device=DEV)
+    out = torch.empty_like(x)
+    _hip.prof_begin()
+    for _ in range(5):
+        ops.rmsnorm(x, w, 1e-5, out)
+    stats = _hip.prof_end()
+    assert set(stats) == {"rmsnorm"} and stats["rmsnorm"][1] == 5 and 0 < stats["rmsnorm"][0] < 50
