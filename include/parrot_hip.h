@@ -98,8 +98,12 @@ int parrot_w8_gemv(const void* CB, const void* SCB, const void* xq, const void* 
                    int ldo, int N, int K, int epilogue, void* stream);
 
 /* ---- norms (lit_gpt/rmsnorm.py:17-21; torch.nn.LayerNorm via lit_gpt/config.py:86-92) ---- */
+/* rsqrt_mode 0: rsqrt evaluated in fp32 and rounded to bf16 once (what torch's GPU kernels do);
+ * 1: sqrt rounded to bf16, then its reciprocal rounded to bf16 — torch's CPU scalar path, which is
+ * what a CPU run of the reference does for the one-value-per-row tensor of rmsnorm.py:19-20
+ * (kept for bit-parity tests against CPU-generated golden vectors).                      */
 int parrot_rmsnorm(const void* x, int ldx, const void* weight, void* out, int ldo, int M, int d,
-                   float eps, void* stream);
+                   float eps, int rsqrt_mode, void* stream);
 int parrot_layernorm(const void* x, int ldx, const void* weight, const void* bias, void* out, int ldo,
                      int M, int d, float eps, void* stream);
 

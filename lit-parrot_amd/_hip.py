@@ -37,7 +37,7 @@ SIGNATURES = {
     "parrot_w8_quantize_rows": (_i, [_vp, _i, _i, _vp, _vp, _vp]),
     "parrot_w8_prep_act": (_i, [_vp, _i, _i, _i, _f, _vp, _vp, _vp, _vp, _vp]),
     "parrot_w8_gemv": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _vp, _i, _i, _i, _i, _vp]),
-    "parrot_rmsnorm": (_i, [_vp, _i, _vp, _vp, _i, _i, _i, _f, _vp]),
+    "parrot_rmsnorm": (_i, [_vp, _i, _vp, _vp, _i, _i, _i, _f, _i, _vp]),
     "parrot_layernorm": (_i, [_vp, _i, _vp, _vp, _vp, _i, _i, _i, _f, _vp]),
     "parrot_qkv_rope_kvappend": (_i, [_vp, _i, _i, _vp, _vp, _i, _i, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "parrot_attn_workspace_floats": (_i64, [_i, _i, _i, _i]),

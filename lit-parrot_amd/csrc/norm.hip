@@ -28,7 +28,7 @@ __device__ __forceinline__ float block_sum(float v, float* sh) {
 template <bool RMS>
 __global__ void __launch_bounds__(kNormThreads)
 norm_kernel(const bf16_t* __restrict__ x, int ldx, const bf16_t* __restrict__ weight, const bf16_t* __restrict__ bias,
-            bf16_t* __restrict__ out, int ldo, int d, float eps) {
+            bf16_t* __restrict__ out, int ldo, int d, float eps, int rsqrt_mode) {
     __shared__ float sh[kNormThreads / 64];
     const int chunks = d >> 3;
     const uint4* xp = reinterpret_cast<const uint4*>(x + (int64_t)blockIdx.x * ldx);
@@ -52,7 +52,10 @@ norm_kernel(const bf16_t* __restrict__ x, int ldx, const bf16_t* __restrict__ we
     float mean = 0.f, r;
     if (RMS) {
         const float ms = rbf(s / (float)d);
-        r = rbf(1.0f / sqrtf(rbf(ms + eps)));
+        const float t = rbf(ms + eps);
+        // rsqrt_mode 0: one rounding (torch's GPU kernel).  1: torch's CPU scalar path for < 16-element tensors
+        // (one value per token row): sqrt rounded to bf16, then the reciprocal rounded again.
+        r = rsqrt_mode ? rbf(__fdiv_rn(1.0f, rbf(sqrtf(t)))) : rbf(__fdiv_rn(1.0f, sqrtf(t)));
     } else {
         mean = s / (float)d;
         float q = 0.f;
@@ -121,11 +124,11 @@ using namespace parrot;
 extern "C" {
 
 int parrot_rmsnorm(const void* x, int ldx, const void* weight, void* out, int ldo, int M, int d, float eps,
-                   void* stream) {
+                   int rsqrt_mode, void* stream) {
     const int rc = norm_check("rmsnorm", x, ldx, weight, out, ldo, M, d);
     if (rc != PARROT_OK) return rc;
     return launch(K_RMSNORM, norm_kernel<true>, dim3(M), dim3(kNormThreads), 0, (hipStream_t)stream, (const bf16_t*)x, ldx,
-                  (const bf16_t*)weight, (const bf16_t*)nullptr, (bf16_t*)out, ldo, d, eps);
+                  (const bf16_t*)weight, (const bf16_t*)nullptr, (bf16_t*)out, ldo, d, eps, rsqrt_mode);
 }
 
 int parrot_layernorm(const void* x, int ldx, const void* weight, const void* bias, void* out, int ldo, int M, int d,
@@ -134,7 +137,7 @@ int parrot_layernorm(const void* x, int ldx, const void* weight, const void* bia
     if (rc != PARROT_OK) return rc;
     PARROT_REQUIRE(!bias || aligned16(bias), "layernorm: bias must be 16-byte aligned");
     return launch(K_LAYERNORM, norm_kernel<false>, dim3(M), dim3(kNormThreads), 0, (hipStream_t)stream, (const bf16_t*)x,
-                  ldx, (const bf16_t*)weight, (const bf16_t*)bias, (bf16_t*)out, ldo, d, eps);
+                  ldx, (const bf16_t*)weight, (const bf16_t*)bias, (bf16_t*)out, ldo, d, eps, 0);
 }
 
 }  // extern "C"

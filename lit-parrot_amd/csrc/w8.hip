@@ -34,9 +34,9 @@ w8_quantize_rows_kernel(const bf16_t* __restrict__ W, int K, int8_t* __restrict_
     float mx = 0.f;
     for (int k = threadIdx.x; k < K; k += 256) mx = fmaxf(mx, fabsf(rhalf(bf2f(w[k]))));
     mx = block_max_256(mx, sh);
-    const float inv = mx > 0.f ? 127.0f / mx : 0.f;
+    const float inv = mx > 0.f ? __fdiv_rn(127.0f, mx) : 0.f;  // correctly rounded, like the host oracle
     for (int k = threadIdx.x; k < K; k += 256)
-        CB[(int64_t)blockIdx.x * K + k] = (int8_t)rintf(rhalf(bf2f(w[k])) * inv);
+        CB[(int64_t)blockIdx.x * K + k] = (int8_t)rintf(__fmul_rn(rhalf(bf2f(w[k])), inv));
     if (threadIdx.x == 0) SCB[blockIdx.x] = mx;
 }
 
@@ -55,12 +55,12 @@ w8_prep_act_kernel(const bf16_t* __restrict__ x, int ldx, int K, float threshold
         if (!(threshold > 0.f && fabsf(a) >= threshold)) mx = fmaxf(mx, fabsf(a));
     }
     mx = block_max_256(mx, sh);
-    const float inv = mx > 0.f ? 127.0f / mx : 0.f;
+    const float inv = mx > 0.f ? __fdiv_rn(127.0f, mx) : 0.f;  // correctly rounded, like the host oracle
     int local = 0;
     for (int k = threadIdx.x; k < K; k += 256) {
         const float a = rhalf(bf2f(xr[k]));
         const bool outlier = threshold > 0.f && fabsf(a) >= threshold;
-        xq[(int64_t)m * K + k] = outlier ? (int8_t)0 : (int8_t)rintf(a * inv);
+        xq[(int64_t)m * K + k] = outlier ? (int8_t)0 : (int8_t)rintf(__fmul_rn(a, inv));
         xout[(int64_t)m * K + k] = outlier ? a : 0.f;
         local += outlier ? 1 : 0;
     }

@@ -22,7 +22,7 @@ MM_DEQUANT = 6.200012e-05  # 1 / (127 * 127) as the float constant
 def quantize_weight_rows(weight: torch.Tensor) -> Tuple[torch.Tensor, torch.Tensor]:
     w = weight.half().float()
     absmax = w.abs().amax(dim=1)
-    inv = torch.where(absmax > 0, 127.0 / absmax, torch.zeros_like(absmax))
+    inv = torch.where(absmax > 0, torch.full_like(absmax, 127.0) / absmax, torch.zeros_like(absmax))  # IEEE division
     CB = torch.round(w * inv[:, None]).to(torch.int8)  # rint: half to even
     return CB, absmax
 
@@ -32,7 +32,7 @@ def quantize_act_rows(x: torch.Tensor, threshold: float):
     outlier = (a.abs() >= threshold) if threshold > 0 else torch.zeros_like(a, dtype=torch.bool)
     kept = torch.where(outlier, torch.zeros_like(a), a)
     absmax = kept.abs().amax(dim=-1)
-    inv = torch.where(absmax > 0, 127.0 / absmax, torch.zeros_like(absmax))
+    inv = torch.where(absmax > 0, torch.full_like(absmax, 127.0) / absmax, torch.zeros_like(absmax))  # (scalar / tensor is reciprocal * scalar in torch)
     CA = torch.round(kept * inv[..., None]).to(torch.int8)
     return CA, absmax, torch.where(outlier, a, torch.zeros_like(a))
 

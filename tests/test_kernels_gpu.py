@@ -216,7 +216,23 @@ def test_rmsnorm_matches_reference_choreography(d):
     w = (1 + 0.1 * torch.randn(d, generator=g)).to(BF)
     out = torch.empty((3, d), dtype=BF, device=DEV)
     ops.rmsnorm(x.to(DEV), w.to(DEV), 1e-5, out)
-    assert_bf16_close(out, om.rms_norm(x, w, 1e-5).float(), ulps=1, what="rmsnorm")  # summation order only
+    # The reference's op sequence with torch's *GPU* semantics for rsqrt: computed in fp32 and rounded once.  torch's CPU
+    # kernel takes a scalar path for tensors of < 16 elements (one value per token row here) that rounds sqrt() to bf16
+    # before the reciprocal, so the CPU oracle can sit 1-2 bf16 ulp away on whole rows; see DESIGN.md §6.
+    xf = x.float()
+    ms = rbf((rbf(xf * xf)).sum(-1, keepdim=True) / d)
+    r = rbf(1.0 / torch.sqrt(rbf(ms + 1e-5)))
+    want = w.float() * rbf(xf * r)
+    assert_bf16_close(out, want, ulps=1, what="rmsnorm")  # <= 1 ulp: the fp32 sum of squares is ordered differently
+    assert float((out.cpu().float() == want.to(BF).float()).float().mean()) > 0.98
+    assert_bf16_close(out, om.rms_norm(x, w, 1e-5).float(), ulps=3, what="rmsnorm vs CPU oracle")
+    # rsqrt_mode 1 reproduces the CPU scalar path: now the CPU oracle itself is matched to the ulp
+    try:
+        ops.RMSNORM_RSQRT_MODE = 1
+        ops.rmsnorm(x.to(DEV), w.to(DEV), 1e-5, out)
+    finally:
+        ops.RMSNORM_RSQRT_MODE = 0
+    assert_bf16_close(out, om.rms_norm(x, w, 1e-5).float(), ulps=1, what="rmsnorm (cpu rsqrt mode) vs CPU oracle")
     assert float((out.cpu() == om.rms_norm(x, w, 1e-5)).float().mean()) > 0.98
 
 
