@@ -42,6 +42,16 @@ extern "C" {
 #define PARROT_EPI_GELU 2     /* out = bf16(gelu_erf(bf16(acc + bias)))   model.py:284-287 */
 #define PARROT_EPI_SWIGLU 3   /* out = bf16(bf16(silu(bf16(acc1))) * bf16(acc2)) model.py:297-301 (needs 2nd weight) */
 
+/* Optional norm fused in front of a Linear (norm_1 / norm_2 / ln_f of lit_gpt/model.py:167,170,178,109): the
+ * Linear's input rows are normalised on the fly.  Host struct, device pointers inside; NULL or kind 0 = none. */
+typedef struct parrot_norm {
+    int kind;           /* 0 none, 1 RMSNorm (lit_gpt/rmsnorm.py), 2 LayerNorm (torch.nn.LayerNorm) */
+    const void* weight; /* bf16 [K] */
+    const void* bias;   /* bf16 [K] or NULL (LayerNorm only) */
+    float eps;
+    int rsqrt_mode;     /* RMSNorm only, see parrot_rmsnorm */
+} parrot_norm_t;
+
 int parrot_version(void);
 const char* parrot_last_error(void);
 
@@ -67,20 +77,20 @@ int parrot_w4_repack(void* quant_weight_ref, void* scales, void* zeros, int N, i
  * packed2 is the second weight of PARROT_EPI_SWIGLU (fc_2), else NULL.           */
 int parrot_w4_gemv(const void* packed, const void* packed2, const void* x, int ldx, int M,
                    const void* bias, const void* residual, int ldr, void* out, int ldo, int N,
-                   int K, int group, int epilogue, void* stream);
+                   int K, int group, int epilogue, const parrot_norm_t* norm, void* stream);
 /* same contract for any M (prefill): MFMA path, dequant-to-LDS */
 int parrot_w4_gemm(const void* packed, const void* packed2, const void* x, int ldx, int M,
                    const void* bias, const void* residual, int ldr, void* out, int ldo, int N,
-                   int K, int group, int epilogue, void* stream);
+                   int K, int group, int epilogue, const parrot_norm_t* norm, void* stream);
 
 /* ---- dense bf16 Linear (torch.nn.Linear on the bf16 path, lit_gpt/model.py:29,188,190,281-295)
  * W is (N, K) row-major bf16.                                                    */
 int parrot_bf16_gemv(const void* W, const void* W2, const void* x, int ldx, int M, const void* bias,
                      const void* residual, int ldr, void* out, int ldo, int N, int K, int epilogue,
-                     void* stream);
+                     const parrot_norm_t* norm, void* stream);
 int parrot_bf16_gemm(const void* W, const void* W2, const void* x, int ldx, int M, const void* bias,
                      const void* residual, int ldr, void* out, int ldo, int N, int K, int epilogue,
-                     void* stream);
+                     const parrot_norm_t* norm, void* stream);
 
 /* ---- LLM.int8 (quantize/bnb.py:18-60; arithmetic = bitsandbytes MatMul8bitLt) ----
  * quantize rows of a bf16/fp16-valued weight: CB = rne(127*W/absmax_row), SCB = absmax_row (fp32) */
@@ -89,7 +99,7 @@ int parrot_w8_quantize_rows(const void* W_bf16, int N, int K, void* CB_int8, voi
  * (kept in 16-bit, zero in the int8 copy), absmax-quantise the rest.
  * xq int8 [M][K]; xout fp32 [M][K] (the outlier values, 0 elsewhere); sca fp32 [M]; nout int32 [M] */
 int parrot_w8_prep_act(const void* x, int ldx, int M, int K, float threshold, void* xq, void* xout,
-                       void* sca, void* nout, void* stream);
+                       void* sca, void* nout, const parrot_norm_t* norm, void* stream);
 /* out = epilogue(cast_bf16(fp16(fp16(C32*SCA*SCB/127^2 + bias) + fp16(outlier_part)))).
  * For PARROT_EPI_SWIGLU the second weight (fc_2) follows the first in the same buffers:
  * CB holds 2N rows ([fc_1; fc_2]) and SCB 2N scales. */
@@ -126,6 +136,14 @@ int64_t parrot_attn_workspace_floats(int M, int n_head, int hs, int nsplit);
 int parrot_attn_decode(const void* q, int M, const int32_t* pos, const void* k_cache,
                        const void* v_cache, int n_groups, int q_per_kv, int hs, int S, int nsplit,
                        void* workspace, void* y, int ldy, void* stream);
+
+/* Decode step (one new token) of CausalSelfAttention in ONE launch: q/k/v split + RoPE + KV append + attention over
+ * slots 0..min(*pos, S-1) + cross-split combine (lit_gpt/model.py:208-247).  qkv: one row; y: [n_head*hs] bf16.
+ * workspace as for parrot_attn_decode (M = 1); tickets: n_groups zero-initialised uint32 (re-armed by the kernel). */
+int parrot_attn_fused_decode(const void* qkv, const void* rope_cos, const void* rope_sin, int n_elem,
+                             const int32_t* pos, int n_groups, int q_per_kv, int hs, int S, int nsplit,
+                             void* workspace, void* tickets, void* k_cache, void* v_cache, void* y,
+                             void* stream);
 
 /* ---- small ops of the step ----------------------------------------------------------
  * x[m] = wte[tokens[(pos ? *pos : 0) + m]]   (lit_gpt/model.py:99)                    */

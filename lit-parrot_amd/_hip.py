@@ -21,6 +21,15 @@ class ParrotHipError(RuntimeError):
 
 _vp, _i, _i64, _f = C.c_void_p, C.c_int, C.c_int64, C.c_float
 
+
+class ParrotNorm(C.Structure):
+    """``parrot_norm_t`` of include/parrot_hip.h: a norm fused in front of a Linear."""
+
+    _fields_ = [("kind", C.c_int), ("weight", C.c_void_p), ("bias", C.c_void_p), ("eps", C.c_float), ("rsqrt_mode", C.c_int)]
+
+
+_np = C.POINTER(ParrotNorm)
+
 # name -> (restype, argtypes); must list every function include/parrot_hip.h declares
 SIGNATURES = {
     "parrot_version": (_i, []),
@@ -30,18 +39,19 @@ SIGNATURES = {
     "parrot_kernel_name": (C.c_char_p, [_i]),
     "parrot_w4_packed_bytes": (_i64, [_i, _i, _i]),
     "parrot_w4_repack": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _i, _vp]),
-    "parrot_w4_gemv": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _vp]),
-    "parrot_w4_gemm": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _vp]),
-    "parrot_bf16_gemv": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp, _i, _vp, _i, _i, _i, _i, _vp]),
-    "parrot_bf16_gemm": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp, _i, _vp, _i, _i, _i, _i, _vp]),
+    "parrot_w4_gemv": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _np, _vp]),
+    "parrot_w4_gemm": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _np, _vp]),
+    "parrot_bf16_gemv": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp, _i, _vp, _i, _i, _i, _i, _np, _vp]),
+    "parrot_bf16_gemm": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp, _i, _vp, _i, _i, _i, _i, _np, _vp]),
     "parrot_w8_quantize_rows": (_i, [_vp, _i, _i, _vp, _vp, _vp]),
-    "parrot_w8_prep_act": (_i, [_vp, _i, _i, _i, _f, _vp, _vp, _vp, _vp, _vp]),
+    "parrot_w8_prep_act": (_i, [_vp, _i, _i, _i, _f, _vp, _vp, _vp, _vp, _np, _vp]),
     "parrot_w8_gemv": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _vp, _i, _i, _i, _i, _vp]),
     "parrot_rmsnorm": (_i, [_vp, _i, _vp, _vp, _i, _i, _i, _f, _i, _vp]),
     "parrot_layernorm": (_i, [_vp, _i, _vp, _vp, _vp, _i, _i, _i, _f, _vp]),
     "parrot_qkv_rope_kvappend": (_i, [_vp, _i, _i, _vp, _vp, _i, _i, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "parrot_attn_workspace_floats": (_i64, [_i, _i, _i, _i]),
     "parrot_attn_decode": (_i, [_vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _i, _vp]),
+    "parrot_attn_fused_decode": (_i, [_vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     "parrot_embedding": (_i, [_vp, _i, _vp, _vp, _i, _vp, _i, _vp]),
     "parrot_argmax_advance": (_i, [_vp, _i, _vp, _vp, _vp]),
 }

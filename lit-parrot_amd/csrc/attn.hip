@@ -208,6 +208,212 @@ attn_combine_kernel(const float* __restrict__ ws, int nsplit, bf16_t* __restrict
     y[(int64_t)m * ldy + (int64_t)head * HS + d] = f2bf(a / l);
 }
 
+// ------------------------------------------------------------------------------------------ fused decode step
+// One launch per layer for a single new token (M = 1): q/k/v split + RoPE + KV append + attention over the cache +
+// the cross-split combine.  Replaces rope_kvappend + attn_decode + attn_combine (3 launches) on the decode path.
+//   * every workgroup (group g, split j) ropes q, k_new, v_new of its group itself (a few hundred elements);
+//   * the workgroup whose slot range contains slot(pos) writes the new K/V row to the cache; in the loop that row is
+//     taken from registers, never from the global copy that is being written;
+//   * partial softmax states go to the workspace with write-through (agent-scope) stores; an arrival ticket per group
+//     elects the last workgroup, which merges the splits (guide recipe: sc1 payload -> every wave vmcnt(0) -> barrier
+//     -> one relaxed agent atomic; reducer reads with agent-scope loads).  The ticket is reset by the reducer.
+constexpr int kFusedMaxQ = 16;  // query heads per group held in LDS
+
+__device__ __forceinline__ void store_agent(float* p, float v) {
+    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ float load_agent(const float* p) {
+    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+template <int HS, int HQ>
+__global__ void __launch_bounds__(kAttnWaves * 64)
+attn_fused_decode_kernel(const bf16_t* __restrict__ qkv, const __half* __restrict__ rope_cos,
+                         const __half* __restrict__ rope_sin, int n_elem, const int32_t* __restrict__ pos_ptr,
+                         bf16_t* __restrict__ k_cache, bf16_t* __restrict__ v_cache, int n_groups, int q_per_kv, int S,
+                         int nsplit, float* __restrict__ ws, unsigned int* __restrict__ tickets, bf16_t* __restrict__ y) {
+    constexpr int LPR = HS / 8;
+    constexpr int RPW = 64 / LPR;
+    constexpr int NSLOT = kAttnWaves * RPW;
+    __shared__ float sh_acc[HQ][NSLOT][HS];
+    __shared__ float sh_m[HQ][NSLOT], sh_l[HQ][NSLOT];
+    __shared__ float sh_q[kFusedMaxQ][HS];  // roped, bf16-rounded, pre-scaled by 1/sqrt(hs)
+    __shared__ __attribute__((aligned(16))) bf16_t sh_kv[2][HS];  // roped k_new, v_new as stored in the cache
+    __shared__ int sh_last;
+
+    const int g = blockIdx.x, split = blockIdx.y;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int sub = lane / LPR, dl = lane % LPR;
+    const int n_head = n_groups * q_per_kv;
+    const int pos = pos_ptr[0];
+    const int n_valid = min(pos + 1, S);
+    const int slot_new = pos % S;
+    const int per = (S + nsplit - 1) / nsplit;
+    const int s_begin = split * per, s_end = min(n_valid, s_begin + per);
+    const float scale = 1.0f / sqrtf((float)HS);
+    const int half_n = n_elem >> 1;
+
+    // ---- split + RoPE of this group's rows (reference model.py:208-232)
+    const bf16_t* grp = qkv + (int64_t)g * (q_per_kv + 2) * HS;
+    for (int idx = threadIdx.x; idx < (q_per_kv + 2) * HS; idx += kAttnWaves * 64) {
+        const int t = idx / HS, d = idx % HS;
+        float v = bf2f(grp[idx]);
+        if (t <= q_per_kv && d < n_elem) {
+            const float c = __half2float(rope_cos[(int64_t)pos * n_elem + d]);
+            const float sn = __half2float(rope_sin[(int64_t)pos * n_elem + d]);
+            const float other = d < half_n ? -bf2f(grp[idx + half_n]) : bf2f(grp[idx - half_n]);
+            v = __fadd_rn(__fmul_rn(v, c), __fmul_rn(other, sn));
+        }
+        const bf16_t vb = f2bf(v);
+        if (t < q_per_kv)
+            sh_q[t][d] = bf2f(vb) * scale;
+        else
+            sh_kv[t - q_per_kv][d] = vb;
+    }
+    __syncthreads();
+    // ---- KV append by the workgroup that owns the new slot
+    if (slot_new >= s_begin && slot_new < s_begin + per && threadIdx.x < 2 * LPR) {
+        const int which = threadIdx.x / LPR, c = threadIdx.x % LPR;
+        bf16_t* dst = (which ? v_cache : k_cache) + ((int64_t)g * S + slot_new) * HS;
+        reinterpret_cast<uint4*>(dst)[c] = reinterpret_cast<const uint4*>(sh_kv[which])[c];
+    }
+    const uint4 knew = reinterpret_cast<const uint4*>(sh_kv[0])[dl];
+    const uint4 vnew = reinterpret_cast<const uint4*>(sh_kv[1])[dl];
+    const uint4* kc = reinterpret_cast<const uint4*>(k_cache + (int64_t)g * S * HS);
+    const uint4* vc = reinterpret_cast<const uint4*>(v_cache + (int64_t)g * S * HS);
+    const int slot = wave * RPW + sub;
+
+    for (int h0 = 0; h0 < q_per_kv; h0 += HQ) {
+        float qf[HQ][8];
+        float mrun[HQ], lrun[HQ], acc[HQ][8];
+#pragma unroll
+        for (int hh = 0; hh < HQ; ++hh) {
+            const int hq = min(h0 + hh, q_per_kv - 1);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) qf[hh][e] = sh_q[hq][dl * 8 + e];
+            mrun[hh] = -INFINITY;
+            lrun[hh] = 0.f;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[hh][e] = 0.f;
+        }
+        for (int s0 = s_begin + wave * RPW; s0 < s_end; s0 += kAttnWaves * RPW) {
+            const int s = s0 + sub;
+            const bool ok = s < s_end;
+            const int sc = ok ? s : s_end - 1;
+            uint4 kv = kc[(int64_t)sc * LPR + dl];
+            uint4 vv = vc[(int64_t)sc * LPR + dl];
+            if (sc == slot_new) {  // the row being appended by this launch: use the in-register copy
+                kv = knew;
+                vv = vnew;
+            }
+            const uint32_t kd[4] = {kv.x, kv.y, kv.z, kv.w};
+            const uint32_t vd[4] = {vv.x, vv.y, vv.z, vv.w};
+            float kf[8], vf[8];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                kf[2 * j] = bflo(kd[j]);
+                kf[2 * j + 1] = bfhi(kd[j]);
+                vf[2 * j] = bflo(vd[j]);
+                vf[2 * j + 1] = bfhi(vd[j]);
+            }
+#pragma unroll
+            for (int hh = 0; hh < HQ; ++hh) {
+                float sc_ = 0.f;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) sc_ = fmaf(qf[hh][e], kf[e], sc_);
+#pragma unroll
+                for (int off = LPR / 2; off >= 1; off >>= 1) sc_ += __shfl_xor(sc_, off, 64);
+                if (ok) {
+                    const float mn = fmaxf(mrun[hh], sc_);
+                    const float corr = __expf(mrun[hh] - mn);
+                    const float p = __expf(sc_ - mn);
+                    lrun[hh] = lrun[hh] * corr + p;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) acc[hh][e] = acc[hh][e] * corr + p * vf[e];
+                    mrun[hh] = mn;
+                }
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int hh = 0; hh < HQ; ++hh) {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) sh_acc[hh][slot][dl * 8 + e] = acc[hh][e];
+            if (dl == 0) {
+                sh_m[hh][slot] = mrun[hh];
+                sh_l[hh][slot] = lrun[hh];
+            }
+        }
+        __syncthreads();
+        for (int idx = threadIdx.x; idx < HQ * HS; idx += kAttnWaves * 64) {
+            const int hh = idx / HS, d = idx % HS;
+            if (h0 + hh < q_per_kv) {
+                float mx = -INFINITY;
+                for (int t = 0; t < NSLOT; ++t) mx = fmaxf(mx, sh_m[hh][t]);
+                float l = 0.f, a = 0.f;
+                for (int t = 0; t < NSLOT; ++t) {
+                    const float mt = sh_m[hh][t];
+                    const float wgt = (mt == -INFINITY) ? 0.f : __expf(mt - mx);
+                    l += sh_l[hh][t] * wgt;
+                    a += sh_acc[hh][t][d] * wgt;
+                }
+                const int head = g * q_per_kv + h0 + hh;
+                if (nsplit == 1) {
+                    y[(int64_t)head * HS + d] = f2bf(a / l);
+                } else {
+                    float* p = ws + ((int64_t)head * nsplit + split) * (HS + 2);
+                    store_agent(p + d, a);
+                    if (d == 0) {
+                        store_agent(p + HS, mx);
+                        store_agent(p + HS + 1, l);
+                    }
+                }
+            }
+        }
+    }
+    if (nsplit == 1) return;
+    // ---- arrival ticket: the last workgroup of this group merges the splits
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every storing wave drains its write-through stores
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned int t = __hip_atomic_fetch_add(&tickets[g], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        sh_last = (t == (unsigned int)(nsplit - 1));
+        if (sh_last) __hip_atomic_store(&tickets[g], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // re-arm
+    }
+    __syncthreads();
+    if (!sh_last) return;
+    for (int idx = threadIdx.x; idx < q_per_kv * HS; idx += kAttnWaves * 64) {
+        const int hq = idx / HS, d = idx % HS;
+        const int head = g * q_per_kv + hq;
+        const float* p = ws + (int64_t)head * nsplit * (HS + 2);
+        float mx = -INFINITY;
+        for (int t = 0; t < nsplit; ++t) mx = fmaxf(mx, load_agent(p + t * (HS + 2) + HS));
+        float l = 0.f, a = 0.f;
+        for (int t = 0; t < nsplit; ++t) {
+            const float mt = load_agent(p + t * (HS + 2) + HS);
+            const float wgt = (mt == -INFINITY) ? 0.f : __expf(mt - mx);
+            l += load_agent(p + t * (HS + 2) + HS + 1) * wgt;
+            a += load_agent(p + t * (HS + 2) + d) * wgt;
+        }
+        y[(int64_t)head * HS + d] = f2bf(a / l);
+    }
+}
+
+template <int HS>
+static int attn_fused_launch(const void* qkv, const void* cosp, const void* sinp, int n_elem, const int32_t* pos,
+                             void* k_cache, void* v_cache, int n_groups, int q_per_kv, int S, int nsplit, void* ws,
+                             void* tickets, void* y, hipStream_t st) {
+    const dim3 grid(n_groups, nsplit), block(kAttnWaves * 64);
+#define PARROT_FUSED_GO(HQV)                                                                                          \
+    return launch(K_ATTN_FUSED, attn_fused_decode_kernel<HS, HQV>, grid, block, 0, st, (const bf16_t*)qkv,            \
+                  (const __half*)cosp, (const __half*)sinp, n_elem, pos, (bf16_t*)k_cache, (bf16_t*)v_cache, n_groups, \
+                  q_per_kv, S, nsplit, (float*)ws, (unsigned int*)tickets, (bf16_t*)y)
+    if (q_per_kv == 1) PARROT_FUSED_GO(1);
+    if (q_per_kv == 2) PARROT_FUSED_GO(2);
+    PARROT_FUSED_GO(4);
+#undef PARROT_FUSED_GO
+}
+
 template <int HS>
 static int attn_launch(const void* q, int M, const int32_t* pos, const void* k_cache, const void* v_cache, int n_groups,
                        int q_per_kv, int S, int nsplit, void* ws, void* y, int ldy, hipStream_t st) {
@@ -249,6 +455,28 @@ int parrot_qkv_rope_kvappend(const void* qkv, int ldqkv, int M, const void* rope
     return launch(K_ROPE_KVAPPEND, rope_kvappend_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
                   (hipStream_t)stream, (const bf16_t*)qkv, ldqkv, M, (const __half*)rope_cos, (const __half*)rope_sin,
                   n_elem, rope_local, pos, n_groups, q_per_kv, hs, S, (bf16_t*)q_out, (bf16_t*)k_cache, (bf16_t*)v_cache);
+}
+
+int parrot_attn_fused_decode(const void* qkv, const void* rope_cos, const void* rope_sin, int n_elem, const int32_t* pos,
+                             int n_groups, int q_per_kv, int hs, int S, int nsplit, void* workspace, void* tickets,
+                             void* k_cache, void* v_cache, void* y, void* stream) {
+    PARROT_REQUIRE(qkv && pos && k_cache && v_cache && y, "attn_fused_decode: null pointer");
+    PARROT_REQUIRE(n_groups >= 1 && q_per_kv >= 1 && S >= 1, "attn_fused_decode: bad shape");
+    PARROT_UNSUPPORTED(q_per_kv <= kFusedMaxQ, "attn_fused_decode: at most %d query heads per group (got %d)", kFusedMaxQ, q_per_kv);
+    PARROT_REQUIRE(n_elem % 2 == 0 && n_elem >= 0 && n_elem <= hs, "attn_fused_decode: bad n_elem=%d", n_elem);
+    PARROT_REQUIRE(n_elem == 0 || (rope_cos && rope_sin), "attn_fused_decode: rope tables missing");
+    PARROT_REQUIRE(nsplit >= 1 && nsplit <= 65535, "attn_fused_decode: nsplit out of range");
+    PARROT_REQUIRE(nsplit == 1 || (workspace && tickets), "attn_fused_decode: workspace and tickets required when nsplit > 1");
+    PARROT_REQUIRE(aligned16(qkv) && aligned16(k_cache) && aligned16(v_cache), "attn_fused_decode: 16-byte alignment");
+    hipStream_t st = (hipStream_t)stream;
+    switch (hs) {
+        case 32: return attn_fused_launch<32>(qkv, rope_cos, rope_sin, n_elem, pos, k_cache, v_cache, n_groups, q_per_kv, S, nsplit, workspace, tickets, y, st);
+        case 64: return attn_fused_launch<64>(qkv, rope_cos, rope_sin, n_elem, pos, k_cache, v_cache, n_groups, q_per_kv, S, nsplit, workspace, tickets, y, st);
+        case 128: return attn_fused_launch<128>(qkv, rope_cos, rope_sin, n_elem, pos, k_cache, v_cache, n_groups, q_per_kv, S, nsplit, workspace, tickets, y, st);
+        default: break;
+    }
+    set_error("attn_fused_decode: head size %d not built (32, 64, 128)", hs);
+    return PARROT_EUNSUPPORTED;
 }
 
 int64_t parrot_attn_workspace_floats(int M, int n_head, int hs, int nsplit) {

@@ -18,9 +18,10 @@ template <int M, bool DUAL, int J>
 __global__ void __launch_bounds__(512)
 bf16_gemv_kernel(const uint4* __restrict__ W, const uint4* __restrict__ W2, const bf16_t* __restrict__ x, int ldx,
                  const bf16_t* __restrict__ bias, const bf16_t* residual, int ldr, bf16_t* out, int ldo, int N, int K,
-                 int rows_per_wg, int epi, int nslabs) {
+                 int rows_per_wg, int epi, int nslabs, NormArgs na) {
     constexpr int NW = DUAL ? 2 : 1;
     __shared__ float red[kDenseMaxSlabs][kDenseMaxRows * M * NW];
+    __shared__ float stat[16];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int chunks = K >> 3;  // 16-B units per row
@@ -44,6 +45,38 @@ bf16_gemv_kernel(const uint4* __restrict__ W, const uint4* __restrict__ W2, cons
             xr[m][j][3] = v.w;
         }
     }
+    if (na.kind != 0) {  // fused RMSNorm / LayerNorm of the input rows (wave-uniform branch)
+#pragma unroll
+        for (int m = 0; m < M; ++m) {
+            float s1 = 0.f;
+#pragma unroll
+            for (int j = 0; j < J; ++j)
+#pragma unroll
+                for (int i = 0; i < 4; ++i) s1 += norm_stat1(xr[m][j][i], na.kind);  // lanes past the slab hold zeros
+            s1 = block_sum_waves(s1, stat, nslabs);
+            float mean = 0.f, r;
+            if (na.kind == 2) {
+                mean = s1 / (float)na.d;
+                float s2 = 0.f;
+#pragma unroll
+                for (int j = 0; j < J; ++j)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) s2 += cok[j] ? norm_stat2(xr[m][j][i], mean) : 0.f;
+                r = norm_scale(na, block_sum_waves(s2, stat, nslabs));
+            } else {
+                r = norm_scale(na, s1);
+            }
+#pragma unroll
+            for (int j = 0; j < J; ++j) {
+                const uint4 wv = reinterpret_cast<const uint4*>(na.weight)[cidx[j]];
+                uint4 bv = make_uint4(0, 0, 0, 0);
+                if (na.kind == 2 && na.bias != nullptr) bv = reinterpret_cast<const uint4*>(na.bias)[cidx[j]];
+                const uint32_t ww[4] = {wv.x, wv.y, wv.z, wv.w}, bb[4] = {bv.x, bv.y, bv.z, bv.w};
+#pragma unroll
+                for (int i = 0; i < 4; ++i) xr[m][j][i] = cok[j] ? norm_apply(xr[m][j][i], ww[i], bb[i], na.kind, mean, r) : 0u;
+            }
+        }
+    }
     const int r_begin = blockIdx.x * rows_per_wg;
     const int r_end = min(N, r_begin + rows_per_wg);
     const int64_t row16 = chunks;
@@ -57,8 +90,8 @@ bf16_gemv_kernel(const uint4* __restrict__ W, const uint4* __restrict__ W2, cons
             const int64_t row = min(r0 + u, N - 1);
 #pragma unroll
             for (int j = 0; j < J; ++j) {
-                w[0][u][j] = W[row * row16 + cidx[j]];
-                if (DUAL) w[1][u][j] = W2[row * row16 + cidx[j]];
+                w[0][u][j] = load_nt16(W + row * row16 + cidx[j]);
+                if (DUAL) w[1][u][j] = load_nt16(W2 + row * row16 + cidx[j]);
             }
         }
 #pragma unroll
@@ -76,8 +109,8 @@ bf16_gemv_kernel(const uint4* __restrict__ W, const uint4* __restrict__ W2, cons
                         p0 = dot2_bf16(ww.z, xr[m][j][2], p0);
                         p1 = dot2_bf16(ww.w, xr[m][j][3], p1);
                     }
-                    const float v = wave_sum(p0 + p1);
-                    if (lane == 0) red[wave][((r0 - r_begin + u) * M + m) * NW + q] = v;
+                    const float v = wave_sum_to_lane63(p0 + p1);
+                    if (lane == 63) red[wave][((r0 - r_begin + u) * M + m) * NW + q] = v;
                 }
     }
     __syncthreads();
@@ -97,7 +130,8 @@ bf16_gemv_kernel(const uint4* __restrict__ W, const uint4* __restrict__ W2, cons
 
 template <int M, int J>
 static int bf16_gemv_launch_j(const void* W, const void* W2, const void* x, int ldx, const void* bias,
-                            const void* residual, int ldr, void* out, int ldo, int N, int K, int epi, hipStream_t st) {
+                              const void* residual, int ldr, void* out, int ldo, int N, int K, int epi, const NormArgs& na,
+                              hipStream_t st) {
     const int chunks = K / 8;
     const int nslabs = (chunks + 64 * kDenseJ - 1) / (64 * kDenseJ);
     const int R = N >= 16 * 2048 ? 16 : (N >= 8 * 1024 ? 8 : 4);
@@ -105,23 +139,24 @@ static int bf16_gemv_launch_j(const void* W, const void* W2, const void* x, int 
     if (epi == PARROT_EPI_SWIGLU)
         return launch(K_BF16_GEMV_DUAL, bf16_gemv_kernel<M, true, J>, grid, block, 0, st, (const uint4*)W, (const uint4*)W2,
                       (const bf16_t*)x, ldx, (const bf16_t*)bias, (const bf16_t*)residual, ldr, (bf16_t*)out, ldo, N, K,
-                      R, epi, nslabs);
+                      R, epi, nslabs, na);
     return launch(K_BF16_GEMV, bf16_gemv_kernel<M, false, J>, grid, block, 0, st, (const uint4*)W, (const uint4*)W2,
                   (const bf16_t*)x, ldx, (const bf16_t*)bias, (const bf16_t*)residual, ldr, (bf16_t*)out, ldo, N, K, R,
-                  epi, nslabs);
+                  epi, nslabs, na);
 }
 
 template <int M>
 static int bf16_gemv_launch(const void* W, const void* W2, const void* x, int ldx, const void* bias,
-                            const void* residual, int ldr, void* out, int ldo, int N, int K, int epi, hipStream_t st) {
+                            const void* residual, int ldr, void* out, int ldo, int N, int K, int epi, const NormArgs& na,
+                            hipStream_t st) {
     const int chunks = K / 8;
     const int nslabs = (chunks + 64 * kDenseJ - 1) / (64 * kDenseJ);
     const int per_slab = (chunks + nslabs - 1) / nslabs;  // 16-B units of the largest slab
     const int jn = (per_slab + 63) / 64;
-    if (jn <= 1) return bf16_gemv_launch_j<M, 1>(W, W2, x, ldx, bias, residual, ldr, out, ldo, N, K, epi, st);
-    if (jn <= 2) return bf16_gemv_launch_j<M, 2>(W, W2, x, ldx, bias, residual, ldr, out, ldo, N, K, epi, st);
-    if (jn <= 4) return bf16_gemv_launch_j<M, 4>(W, W2, x, ldx, bias, residual, ldr, out, ldo, N, K, epi, st);
-    return bf16_gemv_launch_j<M, 8>(W, W2, x, ldx, bias, residual, ldr, out, ldo, N, K, epi, st);
+    if (jn <= 1) return bf16_gemv_launch_j<M, 1>(W, W2, x, ldx, bias, residual, ldr, out, ldo, N, K, epi, na, st);
+    if (jn <= 2) return bf16_gemv_launch_j<M, 2>(W, W2, x, ldx, bias, residual, ldr, out, ldo, N, K, epi, na, st);
+    if (jn <= 4) return bf16_gemv_launch_j<M, 4>(W, W2, x, ldx, bias, residual, ldr, out, ldo, N, K, epi, na, st);
+    return bf16_gemv_launch_j<M, 8>(W, W2, x, ldx, bias, residual, ldr, out, ldo, N, K, epi, na, st);
 }
 
 }  // namespace parrot
@@ -131,12 +166,16 @@ using namespace parrot;
 extern "C" {
 
 int parrot_bf16_gemv(const void* W, const void* W2, const void* x, int ldx, int M, const void* bias,
-                     const void* residual, int ldr, void* out, int ldo, int N, int K, int epilogue, void* stream) {
+                     const void* residual, int ldr, void* out, int ldo, int N, int K, int epilogue,
+                     const parrot_norm_t* norm, void* stream) {
     int rc = check_linear_args("bf16_gemv", W, W2, x, ldx, M, residual, ldr, out, ldo, N, K, epilogue);
     if (rc != PARROT_OK) return rc;
     PARROT_UNSUPPORTED(K % 8 == 0, "bf16_gemv: K=%d must be a multiple of 8", K);
     PARROT_UNSUPPORTED(K <= 64 * 8 * kDenseJ * kDenseMaxSlabs, "bf16_gemv: K=%d too large", K);
     PARROT_UNSUPPORTED(!(epilogue == PARROT_EPI_SWIGLU && bias), "bf16_gemv: SWIGLU epilogue takes no bias");
+    NormArgs na;
+    rc = make_norm_args(norm, K, &na);
+    if (rc != PARROT_OK) return rc;
     hipStream_t st = (hipStream_t)stream;
     const bf16_t* xb = (const bf16_t*)x;
     const bf16_t* rb = (const bf16_t*)residual;
@@ -146,9 +185,9 @@ int parrot_bf16_gemv(const void* W, const void* W2, const void* x, int ldx, int 
         const void* rm = rb ? rb + (int64_t)m0 * ldr : nullptr;
         void* om = ob + (int64_t)m0 * ldo;
         if (M - m0 >= 2)
-            rc = bf16_gemv_launch<2>(W, W2, xm, ldx, bias, rm, ldr, om, ldo, N, K, epilogue, st);
+            rc = bf16_gemv_launch<2>(W, W2, xm, ldx, bias, rm, ldr, om, ldo, N, K, epilogue, na, st);
         else
-            rc = bf16_gemv_launch<1>(W, W2, xm, ldx, bias, rm, ldr, om, ldo, N, K, epilogue, st);
+            rc = bf16_gemv_launch<1>(W, W2, xm, ldx, bias, rm, ldr, om, ldo, N, K, epilogue, na, st);
         if (rc != PARROT_OK) return rc;
     }
     return PARROT_OK;
@@ -156,8 +195,9 @@ int parrot_bf16_gemv(const void* W, const void* W2, const void* x, int ldx, int 
 
 // Prefill entry point.  Round 1: row pairs through the GEMV kernel; the MFMA kernel replaces this body.
 int parrot_bf16_gemm(const void* W, const void* W2, const void* x, int ldx, int M, const void* bias,
-                     const void* residual, int ldr, void* out, int ldo, int N, int K, int epilogue, void* stream) {
-    return parrot_bf16_gemv(W, W2, x, ldx, M, bias, residual, ldr, out, ldo, N, K, epilogue, stream);
+                     const void* residual, int ldr, void* out, int ldo, int N, int K, int epilogue,
+                     const parrot_norm_t* norm, void* stream) {
+    return parrot_bf16_gemv(W, W2, x, ldx, M, bias, residual, ldr, out, ldo, N, K, epilogue, norm, stream);
 }
 
 }  // extern "C"

@@ -64,6 +64,7 @@ enum KernelId : int {
     K_ARGMAX,
     K_W4_GEMM,
     K_BF16_GEMM,
+    K_ATTN_FUSED,
     K_COUNT
 };
 
@@ -113,6 +114,14 @@ __device__ __forceinline__ bf16_t f2bf(float f) {
 // round a float to bf16 precision and come back (the reference's per-op bf16 rounding points)
 __device__ __forceinline__ float rbf(float f) { return bf2f(f2bf(f)); }
 
+// streamed-once data (weights): non-temporal 16-B / 4-B loads
+typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ uint4 load_nt16(const uint4* p) {
+    const u32x4_t v = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(p));
+    return make_uint4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ uint32_t load_nt4(const uint32_t* p) { return __builtin_nontemporal_load(p); }
+
 __device__ __forceinline__ float dot2_bf16(uint32_t a, uint32_t b, float acc) {
     return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2_t, a), __builtin_bit_cast(bf16x2_t, b),
                                            acc, false);
@@ -121,6 +130,21 @@ __device__ __forceinline__ float dot2_bf16(uint32_t a, uint32_t b, float acc) {
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+// DPP move helper: lanes whose row is masked out, or whose source lane is out of range, read 0
+template <int CTRL, int ROW_MASK = 0xF>
+__device__ __forceinline__ float dpp0(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xF, true));
+}
+// Sum over the 64 lanes with DPP only (no LDS crossbar, no waits); the total is valid in LANE 63 only.
+__device__ __forceinline__ float wave_sum_to_lane63(float v) {
+    v += dpp0<0xB1>(v);        // quad_perm [1,0,3,2]
+    v += dpp0<0x4E>(v);        // quad_perm [2,3,0,1]
+    v += dpp0<0x141>(v);       // row_half_mirror
+    v += dpp0<0x140>(v);       // row_mirror: every lane now holds its 16-lane row total
+    v += dpp0<0x142, 0xA>(v);  // row_bcast15 into rows 1 and 3
+    v += dpp0<0x143, 0xC>(v);  // row_bcast31 into rows 2 and 3
     return v;
 }
 __device__ __forceinline__ float wave_max(float v) {
@@ -132,6 +156,79 @@ __device__ __forceinline__ float wave_max(float v) {
 // gelu(x) = 0.5 x (1 + erf(x / sqrt(2))) — torch.nn.functional.gelu default ("none" approximation)
 __device__ __forceinline__ float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
 __device__ __forceinline__ float silu(float x) { return x / (1.0f + expf(-x)); }
+
+// ---------------------------------------------------------------- fused norm prologue of the GEMV kernels
+// The Linear's input rows can be normalised on the fly (norm_1 / norm_2 / ln_f fused into the following Linear):
+// every workgroup recomputes the row statistics from the raw activations it loads anyway (8-64 KB, L2 resident).
+struct NormArgs {
+    int kind;  // 0 none, 1 RMSNorm (lit_gpt/rmsnorm.py:17-21), 2 LayerNorm (torch.nn.LayerNorm)
+    const bf16_t* weight;
+    const bf16_t* bias;  // LayerNorm only, may be null
+    float eps;
+    int rsqrt_mode;  // RMSNorm: see parrot_rmsnorm
+    int d;           // normalised width (= K of the Linear)
+};
+
+inline int make_norm_args(const parrot_norm_t* norm, int K, NormArgs* na) {
+    na->kind = 0;
+    na->weight = nullptr;
+    na->bias = nullptr;
+    na->eps = 0.f;
+    na->rsqrt_mode = 0;
+    na->d = K;
+    if (norm == nullptr || norm->kind == 0) return PARROT_OK;
+    PARROT_REQUIRE(norm->kind == 1 || norm->kind == 2, "norm prologue: kind must be 0, 1 (RMSNorm) or 2 (LayerNorm)");
+    PARROT_REQUIRE(norm->weight != nullptr && aligned16(norm->weight) && (!norm->bias || aligned16(norm->bias)),
+                   "norm prologue: weight/bias must be 16-byte aligned device pointers");
+    na->kind = norm->kind;
+    na->weight = (const bf16_t*)norm->weight;
+    na->bias = (const bf16_t*)norm->bias;
+    na->eps = norm->eps;
+    na->rsqrt_mode = norm->rsqrt_mode;
+    return PARROT_OK;
+}
+
+// sum over all waves of the workgroup (nwaves <= 16); every thread gets the total.  sh: >= 16 floats.
+__device__ __forceinline__ float block_sum_waves(float v, float* sh, int nwaves) {
+    v = wave_sum_to_lane63(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 63) sh[threadIdx.x >> 6] = v;
+    __syncthreads();
+    float t = 0.f;
+    for (int i = 0; i < nwaves; ++i) t += sh[i];
+    return t;
+}
+
+// lane-partial of the first statistic: sum of bf16(x*x) (RMSNorm) or sum of x (LayerNorm)
+__device__ __forceinline__ float norm_stat1(uint32_t packed, int kind) {
+    const float a = bflo(packed), b = bfhi(packed);
+    return kind == 1 ? rbf(a * a) + rbf(b * b) : a + b;
+}
+__device__ __forceinline__ float norm_stat2(uint32_t packed, float mean) {
+    const float a = bflo(packed) - mean, b = bfhi(packed) - mean;
+    return a * a + b * b;
+}
+// finish the statistics: returns the scale r (and mean through *mean for LayerNorm)
+__device__ __forceinline__ float norm_scale(const NormArgs& na, float stat) {
+    if (na.kind == 1) {
+        const float ms = rbf(stat / (float)na.d);
+        const float t = rbf(ms + na.eps);
+        return na.rsqrt_mode ? rbf(__fdiv_rn(1.0f, rbf(sqrtf(t)))) : rbf(__fdiv_rn(1.0f, sqrtf(t)));
+    }
+    return 1.0f / sqrtf(stat / (float)na.d + na.eps);
+}
+// normalise one packed pair with its weight / bias pairs; same rounding points as norm.hip
+__device__ __forceinline__ uint32_t norm_apply(uint32_t x, uint32_t w, uint32_t b, int kind, float mean, float r) {
+    float lo, hi;
+    if (kind == 1) {
+        lo = bflo(w) * rbf(bflo(x) * r);
+        hi = bfhi(w) * rbf(bfhi(x) * r);
+    } else {
+        lo = (bflo(x) - mean) * r * bflo(w) + bflo(b);
+        hi = (bfhi(x) - mean) * r * bfhi(w) + bfhi(b);
+    }
+    return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16);
+}
 
 // shared GEMV epilogue: acc is the fp32 dot product (bias not yet added)
 __device__ __forceinline__ bf16_t apply_epilogue(int epi, float acc, float acc2, const bf16_t* bias,

@@ -144,7 +144,7 @@ w4_repack_kernel(uint8_t* __restrict__ qref, bf16_t* __restrict__ scales, bf16_t
 }
 
 // ------------------------------------------------------------------------------------------ GEMV
-constexpr int kU = 4;         // rows in flight per wave per iteration
+constexpr int kU = 8;         // rows in flight per wave per iteration (all loads issued before the first use)
 constexpr int kMaxRows = 16;  // rows per workgroup
 
 __device__ __forceinline__ float w4_slice_dot(const uint4 w, const uint32_t (&xr)[16]) {
@@ -168,9 +168,10 @@ template <int M, bool DUAL>
 __global__ void __launch_bounds__(1024)
 w4_gemv_kernel(const uint4* __restrict__ W, const uint4* __restrict__ W2, const bf16_t* __restrict__ x, int ldx,
                const bf16_t* __restrict__ bias, const bf16_t* residual, int ldr, bf16_t* out, int ldo, int N,
-               int rows_per_wg, int epi, W4Plan plan) {
+               int rows_per_wg, int epi, NormArgs na, W4Plan plan) {
     constexpr int NW = DUAL ? 2 : 1;
     __shared__ float red[kMaxSlabs][kMaxRows * M * NW];
+    __shared__ float stat[kMaxSlabs];
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -178,14 +179,37 @@ w4_gemv_kernel(const uint4* __restrict__ W, const uint4* __restrict__ W2, const 
     const bool active = lane < sl.nslices;
     const int lslice = active ? lane : sl.nslices - 1;
     const int gslice = sl.slice0 + lslice;
+    const int gl = gslice / plan.Gs - sl.g0;
+    const int64_t row16 = plan.row16;
+    const int r_begin = blockIdx.x * rows_per_wg;
+    const int r_end = min(N, r_begin + rows_per_wg);
 
-    // this lane's 32 activations per row of x, as 16 packed bf16 pairs, and their sum
+    uint4 w[NW][kU];
+    uint32_t mt[NW][kU];
+    // All kU row loads of a batch are issued back to back before anything waits.  Weights are read exactly once per
+    // token: non-temporal loads keep them from displacing the activations in L2.
+#define W4_LOAD_BATCH(R0)                                                                            \
+    _Pragma("unroll") for (int u = 0; u < kU; ++u) {                                                 \
+        const int64_t row = min((R0) + u, N - 1);                                                    \
+        const uint4* rec = W + row * row16;                                                          \
+        w[0][u] = load_nt16(rec + sl.w_off16 + lslice);                                              \
+        mt[0][u] = load_nt4(reinterpret_cast<const uint32_t*>(rec + sl.meta_off16) + gl);           \
+        if (DUAL) {                                                                                  \
+            const uint4* rec2 = W2 + row * row16;                                                    \
+            w[1][u] = load_nt16(rec2 + sl.w_off16 + lslice);                                         \
+            mt[1][u] = load_nt4(reinterpret_cast<const uint32_t*>(rec2 + sl.meta_off16) + gl);       \
+        }                                                                                            \
+    }
+    // the first batch of weights is requested BEFORE the activations: the HBM stream starts at once and the
+    // (L2-resident) activation loads and the norm prologue run under its latency
+    W4_LOAD_BATCH(r_begin)
+
+    // this lane's 32 activations per row of x, as 16 packed bf16 pairs
     uint32_t xr[M][16];
     float xs[M];
 #pragma unroll
     for (int m = 0; m < M; ++m) {
         const uint4* xp = reinterpret_cast<const uint4*>(x + (int64_t)m * ldx + (int64_t)gslice * 32);
-        float s = 0.f;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             uint4 v = xp[j];
@@ -194,30 +218,53 @@ w4_gemv_kernel(const uint4* __restrict__ W, const uint4* __restrict__ W2, const 
             xr[m][4 * j + 1] = v.y;
             xr[m][4 * j + 2] = v.z;
             xr[m][4 * j + 3] = v.w;
-            s += (bflo(v.x) + bfhi(v.x)) + (bflo(v.y) + bfhi(v.y)) + (bflo(v.z) + bfhi(v.z)) + (bflo(v.w) + bfhi(v.w));
         }
+    }
+    if (na.kind != 0) {  // fused RMSNorm / LayerNorm of the input rows (wave-uniform branch)
+        uint32_t nw[16], nb[16];
+        {
+            const uint4* wp = reinterpret_cast<const uint4*>(na.weight + (int64_t)gslice * 32);
+            const uint4* bp = reinterpret_cast<const uint4*>(na.bias + (int64_t)gslice * 32);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const uint4 v = wp[j];
+                nw[4 * j] = v.x; nw[4 * j + 1] = v.y; nw[4 * j + 2] = v.z; nw[4 * j + 3] = v.w;
+                uint4 b = make_uint4(0, 0, 0, 0);
+                if (na.kind == 2 && na.bias != nullptr) b = bp[j];
+                nb[4 * j] = b.x; nb[4 * j + 1] = b.y; nb[4 * j + 2] = b.z; nb[4 * j + 3] = b.w;
+            }
+        }
+#pragma unroll
+        for (int m = 0; m < M; ++m) {
+            float s1 = 0.f;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) s1 += norm_stat1(xr[m][i], na.kind);
+            s1 = block_sum_waves(s1, stat, plan.nslabs);
+            float mean = 0.f, r;
+            if (na.kind == 2) {
+                mean = s1 / (float)na.d;
+                float s2 = 0.f;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) s2 += active ? norm_stat2(xr[m][i], mean) : 0.f;
+                r = norm_scale(na, block_sum_waves(s2, stat, plan.nslabs));
+            } else {
+                r = norm_scale(na, s1);
+            }
+#pragma unroll
+            for (int i = 0; i < 16; ++i) xr[m][i] = active ? norm_apply(xr[m][i], nw[i], nb[i], na.kind, mean, r) : 0u;
+        }
+    }
+#pragma unroll
+    for (int m = 0; m < M; ++m) {
+        float s = 0.f;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) s += bflo(xr[m][i]) + bfhi(xr[m][i]);
         xs[m] = s;
     }
 
-    const int gl = gslice / plan.Gs - sl.g0;
-    const int64_t row16 = plan.row16;
-    const int r_begin = blockIdx.x * rows_per_wg;
-    const int r_end = min(N, r_begin + rows_per_wg);
-
     for (int r0 = r_begin; r0 < r_end; r0 += kU) {
-        uint4 w[NW][kU];
-        uint32_t mt[NW][kU];
-#pragma unroll
-        for (int u = 0; u < kU; ++u) {
-            const int64_t row = min(r0 + u, N - 1);
-            const uint4* rec = W + row * row16;
-            w[0][u] = rec[sl.w_off16 + lslice];
-            mt[0][u] = reinterpret_cast<const uint32_t*>(rec + sl.meta_off16)[gl];
-            if (DUAL) {
-                const uint4* rec2 = W2 + row * row16;
-                w[1][u] = rec2[sl.w_off16 + lslice];
-                mt[1][u] = reinterpret_cast<const uint32_t*>(rec2 + sl.meta_off16)[gl];
-            }
+        if (r0 != r_begin) {
+            W4_LOAD_BATCH(r0)
         }
 #pragma unroll
         for (int u = 0; u < kU; ++u) {
@@ -229,12 +276,13 @@ w4_gemv_kernel(const uint4* __restrict__ W, const uint4* __restrict__ W2, const 
                 for (int m = 0; m < M; ++m) {
                     const float p = w4_slice_dot(w[q][u], xr[m]);
                     float v = s * (p - zz * xs[m]);
-                    v = wave_sum(v);
-                    if (lane == 0) red[wave][((r0 - r_begin + u) * M + m) * NW + q] = v;
+                    v = wave_sum_to_lane63(v);
+                    if (lane == 63) red[wave][((r0 - r_begin + u) * M + m) * NW + q] = v;
                 }
             }
         }
     }
+#undef W4_LOAD_BATCH
     __syncthreads();
     const int nrows = r_end - r_begin;
     if ((int)threadIdx.x < nrows * M) {
@@ -250,25 +298,27 @@ w4_gemv_kernel(const uint4* __restrict__ W, const uint4* __restrict__ W2, const 
     }
 }
 
+static int g_rows_per_wg_override = 0;  // tuning hook (tools/microbench.py), 0 = heuristic
+
 static int pick_rows_per_wg(int N) {
+    if (g_rows_per_wg_override > 0) return g_rows_per_wg_override;
     if (N >= 16 * 2048) return 16;
-    if (N >= 8 * 1024) return 8;
-    return 4;
+    return 8;
 }
 
 template <int M>
 static int w4_gemv_launch(const void* packed, const void* packed2, const void* x, int ldx, const void* bias,
-                          const void* residual, int ldr, void* out, int ldo, int N, int epi, const W4Plan& plan,
-                          hipStream_t st) {
+                          const void* residual, int ldr, void* out, int ldo, int N, int epi, const NormArgs& na,
+                          const W4Plan& plan, hipStream_t st) {
     const int R = pick_rows_per_wg(N);
     const dim3 grid((N + R - 1) / R), block(64 * plan.nslabs);
     if (epi == PARROT_EPI_SWIGLU)
         return launch(K_W4_GEMV_DUAL, w4_gemv_kernel<M, true>, grid, block, 0, st, (const uint4*)packed,
                       (const uint4*)packed2, (const bf16_t*)x, ldx, (const bf16_t*)bias, (const bf16_t*)residual, ldr,
-                      (bf16_t*)out, ldo, N, R, epi, plan);
+                      (bf16_t*)out, ldo, N, R, epi, na, plan);
     return launch(K_W4_GEMV, w4_gemv_kernel<M, false>, grid, block, 0, st, (const uint4*)packed, (const uint4*)packed2,
                   (const bf16_t*)x, ldx, (const bf16_t*)bias, (const bf16_t*)residual, ldr, (bf16_t*)out, ldo, N, R, epi,
-                  plan);
+                  na, plan);
 }
 
 }  // namespace parrot
@@ -276,6 +326,12 @@ static int w4_gemv_launch(const void* packed, const void* packed2, const void* x
 using namespace parrot;
 
 extern "C" {
+
+// tuning hook, not part of the public header: rows of output per workgroup (0 = heuristic)
+int parrot_tune_w4_rows_per_wg(int rows) {
+    g_rows_per_wg_override = (rows == 4 || rows == 8 || rows == 16) ? rows : 0;
+    return PARROT_OK;
+}
 
 int64_t parrot_w4_packed_bytes(int N, int K, int group) {
     W4Plan plan;
@@ -301,12 +357,15 @@ int parrot_w4_repack(void* quant_weight_ref, void* scales, void* zeros, int N, i
 
 int parrot_w4_gemv(const void* packed, const void* packed2, const void* x, int ldx, int M, const void* bias,
                    const void* residual, int ldr, void* out, int ldo, int N, int K, int group, int epilogue,
-                   void* stream) {
+                   const parrot_norm_t* norm, void* stream) {
     int rc = check_linear_args("w4_gemv", packed, packed2, x, ldx, M, residual, ldr, out, ldo, N, K, epilogue);
     if (rc != PARROT_OK) return rc;
     PARROT_UNSUPPORTED(!(epilogue == PARROT_EPI_SWIGLU && bias), "w4_gemv: SWIGLU epilogue takes no bias");
     W4Plan plan;
     rc = w4_make_plan(N, K, group, &plan);
+    if (rc != PARROT_OK) return rc;
+    NormArgs na;
+    rc = make_norm_args(norm, K, &na);
     if (rc != PARROT_OK) return rc;
     hipStream_t st = (hipStream_t)stream;
     const bf16_t* xb = (const bf16_t*)x;
@@ -318,10 +377,10 @@ int parrot_w4_gemv(const void* packed, const void* packed2, const void* x, int l
         const void* rm = rb ? rb + (int64_t)m0 * ldr : nullptr;
         void* om = ob + (int64_t)m0 * ldo;
         switch (mm) {
-            case 1: rc = w4_gemv_launch<1>(packed, packed2, xm, ldx, bias, rm, ldr, om, ldo, N, epilogue, plan, st); break;
-            case 2: rc = w4_gemv_launch<2>(packed, packed2, xm, ldx, bias, rm, ldr, om, ldo, N, epilogue, plan, st); break;
-            case 3: rc = w4_gemv_launch<3>(packed, packed2, xm, ldx, bias, rm, ldr, om, ldo, N, epilogue, plan, st); break;
-            default: rc = w4_gemv_launch<4>(packed, packed2, xm, ldx, bias, rm, ldr, om, ldo, N, epilogue, plan, st); break;
+            case 1: rc = w4_gemv_launch<1>(packed, packed2, xm, ldx, bias, rm, ldr, om, ldo, N, epilogue, na, plan, st); break;
+            case 2: rc = w4_gemv_launch<2>(packed, packed2, xm, ldx, bias, rm, ldr, om, ldo, N, epilogue, na, plan, st); break;
+            case 3: rc = w4_gemv_launch<3>(packed, packed2, xm, ldx, bias, rm, ldr, om, ldo, N, epilogue, na, plan, st); break;
+            default: rc = w4_gemv_launch<4>(packed, packed2, xm, ldx, bias, rm, ldr, om, ldo, N, epilogue, na, plan, st); break;
         }
         if (rc != PARROT_OK) return rc;
     }
@@ -332,8 +391,8 @@ int parrot_w4_gemv(const void* packed, const void* packed2, const void* x, int l
 // the MFMA dequant-to-LDS kernel replaces this body without changing the contract.
 int parrot_w4_gemm(const void* packed, const void* packed2, const void* x, int ldx, int M, const void* bias,
                    const void* residual, int ldr, void* out, int ldo, int N, int K, int group, int epilogue,
-                   void* stream) {
-    return parrot_w4_gemv(packed, packed2, x, ldx, M, bias, residual, ldr, out, ldo, N, K, group, epilogue, stream);
+                   const parrot_norm_t* norm, void* stream) {
+    return parrot_w4_gemv(packed, packed2, x, ldx, M, bias, residual, ldr, out, ldo, N, K, group, epilogue, norm, stream);
 }
 
 }  // extern "C"

@@ -40,25 +40,55 @@ w8_quantize_rows_kernel(const bf16_t* __restrict__ W, int K, int8_t* __restrict_
     if (threadIdx.x == 0) SCB[blockIdx.x] = mx;
 }
 
-// one workgroup per token row.  oidx is the compact list of outlier columns (capacity K per row).
+// one workgroup per token row; optional fused norm of the row (the quantised copy is taken from the normalised values)
 __global__ void __launch_bounds__(256)
 w8_prep_act_kernel(const bf16_t* __restrict__ x, int ldx, int K, float threshold, int8_t* __restrict__ xq,
-                   float* __restrict__ xout, float* __restrict__ sca, int32_t* __restrict__ nout) {
+                   float* __restrict__ xout, float* __restrict__ sca, int32_t* __restrict__ nout, NormArgs na) {
     __shared__ float sh[4];
+    __shared__ float stat[16];
     __shared__ int cnt;
     const int m = blockIdx.x;
     const bf16_t* xr = x + (int64_t)m * ldx;
     if (threadIdx.x == 0) cnt = 0;
+    float mean = 0.f, r = 1.f;
+    if (na.kind != 0) {
+        float s1 = 0.f;
+        for (int k = threadIdx.x; k < K; k += 256) {
+            const float a = bf2f(xr[k]);
+            s1 += na.kind == 1 ? rbf(a * a) : a;
+        }
+        s1 = block_sum_waves(s1, stat, 4);
+        if (na.kind == 2) {
+            mean = s1 / (float)K;
+            float s2 = 0.f;
+            for (int k = threadIdx.x; k < K; k += 256) {
+                const float a = bf2f(xr[k]) - mean;
+                s2 += a * a;
+            }
+            r = norm_scale(na, block_sum_waves(s2, stat, 4));
+        } else {
+            r = norm_scale(na, s1);
+        }
+    }
+    auto value = [&](int k) -> float {
+        float a = bf2f(xr[k]);
+        if (na.kind == 1) {
+            a = rbf(bf2f(na.weight[k]) * rbf(a * r));
+        } else if (na.kind == 2) {
+            a = rbf((a - mean) * r * bf2f(na.weight[k]) + (na.bias ? bf2f(na.bias[k]) : 0.f));
+        }
+        return rhalf(a);
+    };
     float mx = 0.f;
     for (int k = threadIdx.x; k < K; k += 256) {
-        const float a = rhalf(bf2f(xr[k]));
+        const float a = value(k);
         if (!(threshold > 0.f && fabsf(a) >= threshold)) mx = fmaxf(mx, fabsf(a));
     }
     mx = block_max_256(mx, sh);
     const float inv = mx > 0.f ? __fdiv_rn(127.0f, mx) : 0.f;  // correctly rounded, like the host oracle
     int local = 0;
     for (int k = threadIdx.x; k < K; k += 256) {
-        const float a = rhalf(bf2f(xr[k]));
+        const float a = value(k);
         const bool outlier = threshold > 0.f && fabsf(a) >= threshold;
         xq[(int64_t)m * K + k] = outlier ? (int8_t)0 : (int8_t)rintf(__fmul_rn(a, inv));
         xout[(int64_t)m * K + k] = outlier ? a : 0.f;
@@ -195,11 +225,14 @@ int parrot_w8_quantize_rows(const void* W_bf16, int N, int K, void* CB_int8, voi
 }
 
 int parrot_w8_prep_act(const void* x, int ldx, int M, int K, float threshold, void* xq, void* xout, void* sca, void* nout,
-                       void* stream) {
+                       const parrot_norm_t* norm, void* stream) {
     PARROT_REQUIRE(x && xq && xout && sca && nout, "w8_prep_act: null pointer");
     PARROT_REQUIRE(M >= 1 && K >= 1 && ldx >= K, "w8_prep_act: bad shape M=%d K=%d ldx=%d", M, K, ldx);
+    NormArgs na;
+    const int rc = make_norm_args(norm, K, &na);
+    if (rc != PARROT_OK) return rc;
     return launch(K_W8_PREP_ACT, w8_prep_act_kernel, dim3(M), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, ldx, K,
-                  threshold, (int8_t*)xq, (float*)xout, (float*)sca, (int32_t*)nout);
+                  threshold, (int8_t*)xq, (float*)xout, (float*)sca, (int32_t*)nout, na);
 }
 
 // CB / SCB may be followed by a second weight for the SWIGLU epilogue: pass them concatenated as

@@ -10,8 +10,8 @@ checkpoints (``lit_model.pth``, ``lit_model_gptq.4bit.pth``) load by key.
 Execution is different by design: a token row never goes through ~30 small torch ops per layer.  Every module
 contributes its parameters to a fixed sequence of fused kernels per block (``_block_rows``):
 
-    norm_1 -> QKV linear -> [split + RoPE + KV append] -> decode attention -> proj linear (+ residual)
-           -> norm_2 -> MLP up linear (+ GELU | SwiGLU) -> MLP down linear (+ residual)
+    [norm_1 + QKV linear] -> [split + RoPE + KV append + attention + split combine] -> [proj linear + residual]
+        -> [norm_2 + MLP up linear(s) + GELU | SwiGLU] -> [MLP down linear + residual]          (5 launches / layer)
 
 All intermediates live in a per-row-count ``Workspace`` that is allocated once, the position is a device scalar and
 no step reads anything back to the host, so one decode step is a static launch sequence that ``generate`` captures
@@ -51,13 +51,13 @@ class Workspace:
         c = config
         self.M, self.lm_rows = M, lm_rows
         self.x, self.t = buf(c.n_embd), buf(c.n_embd)
-        self.n1, self.n2 = buf(c.n_embd), buf(c.n_embd)
         self.qkv = buf(c.qkv_size)
         self.q = buf(c.n_head * c.head_size)
         self.y = buf(c.n_embd)
         self.h = buf(c.intermediate_size)
         self.logits = buf(c.padded_vocab_size, lm_rows)
         self.zero_pos = torch.zeros((1,), dtype=torch.int32, device=device)
+        self.tickets = torch.zeros((c.n_query_groups,), dtype=torch.int32, device=device)  # fused attention arrival counters
         self._attn_ws = {}
 
     def attn_ws(self, config: Config, nsplit: int) -> torch.Tensor:
@@ -66,17 +66,30 @@ class Workspace:
         return self._attn_ws[nsplit]
 
 
+def _fused_norm(mod: Optional[nn.Module]) -> Optional[ops.Norm]:
+    """Describe a norm module so that the following Linear applies it to its input rows on the fly."""
+    if mod is None:
+        return None
+    if isinstance(mod, RMSNorm):
+        return ops.Norm(1, mod.weight.data, None, mod.eps)
+    if isinstance(mod, nn.LayerNorm):
+        return ops.Norm(2, mod.weight.data, None if mod.bias is None else mod.bias.data, mod.eps)
+    raise ParrotHipError(f"no HIP kernel for norm class {type(mod).__name__}")
+
+
 def _linear(mod: nn.Module, x: torch.Tensor, out: torch.Tensor, *, epilogue: int = EPI_NONE, residual=None,
-            partner: Optional[nn.Module] = None) -> torch.Tensor:
-    """Run one Linear-shaped module on rows with a fused epilogue, whatever class ``quantization()`` installed."""
+            partner: Optional[nn.Module] = None, norm: Optional[nn.Module] = None) -> torch.Tensor:
+    """Run one Linear-shaped module on rows with a fused epilogue — and optionally the norm module in front of it
+    fused as a prologue — whatever class ``quantization()`` installed."""
+    norm = _fused_norm(norm)
     if hasattr(mod, "hip_linear"):
-        return mod.hip_linear(x, out, epilogue=epilogue, residual=residual, partner=partner)
+        return mod.hip_linear(x, out, epilogue=epilogue, residual=residual, partner=partner, norm=norm)
     if isinstance(mod, nn.Linear):
         if partner is not None and not (isinstance(partner, nn.Linear) and not hasattr(partner, "hip_linear")):
             raise ParrotHipError("SwiGLU partner must be the same Linear class")
         return ops.bf16_linear(mod.weight.data, x, out, bias=None if mod.bias is None else mod.bias.data,
                                epilogue=epilogue, residual=residual,
-                               weight2=None if partner is None else partner.weight.data)
+                               weight2=None if partner is None else partner.weight.data, norm=norm)
     raise ParrotHipError(f"no HIP kernel for Linear class {type(mod).__name__}")
 
 
@@ -171,9 +184,8 @@ class GPT(nn.Module):
         nsplit = ops.attn_nsplit(self.config.n_query_groups, S)
         for block, (kc, vc) in zip(self.transformer.h, caches):
             block.run_rows(ws, pos, S, kc, vc, rope, nsplit, rope_local)
-        _norm(self.transformer.ln_f, ws.x, ws.n1)
-        last = ws.n1 if ws.lm_rows == M else ws.n1[M - 1:M]
-        return _linear(self.lm_head, last, ws.logits)
+        last = ws.x if ws.lm_rows == M else ws.x[M - 1:M]
+        return _linear(self.lm_head, last, ws.logits, norm=self.transformer.ln_f)  # ln_f fused into lm_head
 
     def forward(self, idx: torch.Tensor, max_seq_length: Optional[int] = None,
                 input_pos: Optional[torch.Tensor] = None) -> torch.Tensor:
@@ -230,13 +242,12 @@ class Block(nn.Module):
                  rope: RoPECache, nsplit: int, rope_local: bool = False) -> None:
         """One block over ``ws.x`` in place (reference Block.forward, model.py:158-180)."""
         c = self.config
-        _norm(self.norm_1, ws.x, ws.n1)
-        self.attn.run_rows(ws, ws.n1, pos, S, k_cache, v_cache, rope, nsplit, rope_local)  # -> ws.y
+        # norm_1 is fused into the QKV linear, norm_2 into the MLP's first linear: no normalised copy is materialised
+        self.attn.run_rows(ws, ws.x, pos, S, k_cache, v_cache, rope, nsplit, rope_local, norm=self.norm_1)  # -> ws.y
         if c.parallel_residual:
             # x + h + mlp(n_2): the first sum is rounded to bf16 before the second, as in the reference (:171)
             _linear(self.attn.proj, ws.y, ws.t, epilogue=EPI_RESIDUAL, residual=ws.x)
-            n2 = ws.n1 if c.shared_attention_norm else _norm(self.norm_2, ws.x, ws.n2)
-            self.mlp.run_rows(ws, n2, residual=ws.t, out=ws.x)
+            self.mlp.run_rows(ws, ws.x, residual=ws.t, out=ws.x, norm=self.norm_1 if c.shared_attention_norm else self.norm_2)
         else:
             if c.shared_attention_norm:
                 raise NotImplementedError(
@@ -244,8 +255,7 @@ class Block(nn.Module):
                     " (non-parallel residual and shared attention norm)."
                 )
             _linear(self.attn.proj, ws.y, ws.x, epilogue=EPI_RESIDUAL, residual=ws.x)  # x = x + h
-            _norm(self.norm_2, ws.x, ws.n2)
-            self.mlp.run_rows(ws, ws.n2, residual=ws.x, out=ws.x)  # x = x + mlp(norm_2(x))
+            self.mlp.run_rows(ws, ws.x, residual=ws.x, out=ws.x, norm=self.norm_2)  # x = x + mlp(norm_2(x))
 
     def forward(self, x: torch.Tensor, rope: RoPECache, max_seq_length: int, mask: Optional[torch.Tensor] = None,
                 input_pos: Optional[torch.Tensor] = None, kv_cache: Optional[KVCache] = None
@@ -281,11 +291,16 @@ class CausalSelfAttention(nn.Module):
         self.config = config
 
     def run_rows(self, ws: Workspace, x: torch.Tensor, pos: torch.Tensor, S: int, k_cache: torch.Tensor,
-                 v_cache: torch.Tensor, rope: RoPECache, nsplit: int, rope_local: bool = False) -> torch.Tensor:
-        """qkv linear, split + RoPE + cache append, attention over the cache; leaves the heads in ``ws.y``
-        (the output projection is fused with the residual add by the caller)."""
+                 v_cache: torch.Tensor, rope: RoPECache, nsplit: int, rope_local: bool = False,
+                 norm: Optional[nn.Module] = None) -> torch.Tensor:
+        """(norm +) qkv linear, split + RoPE + cache append, attention over the cache; leaves the heads in ``ws.y``
+        (the output projection is fused with the residual add by the caller).  A single new token takes the fused
+        kernel (one launch); several rows (prefill) take rope_kvappend + attn_decode over all rows."""
         c = self.config
-        _linear(self.attn, x, ws.qkv)
+        _linear(self.attn, x, ws.qkv, norm=norm)
+        if ws.M == 1 and not rope_local and c.q_per_kv <= ops.FUSED_ATTN_MAX_Q_PER_KV:
+            return ops.attn_fused_decode(ws.qkv, rope[0], rope[1], c.rope_n_elem, pos, k_cache, v_cache, c.n_query_groups,
+                                         c.q_per_kv, c.head_size, S, nsplit, ws.attn_ws(c, nsplit), ws.tickets, ws.y)
         ops.rope_kvappend(ws.qkv, rope[0], rope[1], c.rope_n_elem, pos, c.n_query_groups, c.q_per_kv, c.head_size, S,
                           ws.q, k_cache, v_cache, rope_local)
         return ops.attn_decode(ws.q, pos, k_cache, v_cache, c.n_query_groups, c.q_per_kv, c.head_size, S, nsplit,
@@ -319,8 +334,9 @@ class GptNeoxMLP(nn.Module):
         self.fc = nn.Linear(config.n_embd, config.intermediate_size, bias=config.bias)
         self.proj = nn.Linear(config.intermediate_size, config.n_embd, bias=config.bias)
 
-    def run_rows(self, ws: Workspace, x: torch.Tensor, *, residual: Optional[torch.Tensor], out: torch.Tensor) -> torch.Tensor:
-        _linear(self.fc, x, ws.h, epilogue=EPI_GELU)  # exact-erf GELU fused (model.py:284-287)
+    def run_rows(self, ws: Workspace, x: torch.Tensor, *, residual: Optional[torch.Tensor], out: torch.Tensor,
+                 norm: Optional[nn.Module] = None) -> torch.Tensor:
+        _linear(self.fc, x, ws.h, epilogue=EPI_GELU, norm=norm)  # exact-erf GELU fused (model.py:284-287)
         return _linear(self.proj, ws.h, out, epilogue=EPI_RESIDUAL if residual is not None else EPI_NONE, residual=residual)
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
@@ -336,8 +352,9 @@ class LLaMAMLP(nn.Module):
         self.fc_2 = nn.Linear(config.n_embd, config.intermediate_size, bias=config.bias)
         self.proj = nn.Linear(config.intermediate_size, config.n_embd, bias=config.bias)
 
-    def run_rows(self, ws: Workspace, x: torch.Tensor, *, residual: Optional[torch.Tensor], out: torch.Tensor) -> torch.Tensor:
-        _linear(self.fc_1, x, ws.h, epilogue=EPI_SWIGLU, partner=self.fc_2)  # silu(fc_1 x) * fc_2 x (model.py:297-301)
+    def run_rows(self, ws: Workspace, x: torch.Tensor, *, residual: Optional[torch.Tensor], out: torch.Tensor,
+                 norm: Optional[nn.Module] = None) -> torch.Tensor:
+        _linear(self.fc_1, x, ws.h, epilogue=EPI_SWIGLU, partner=self.fc_2, norm=norm)  # silu(fc_1 x) * fc_2 x (model.py:297-301)
         return _linear(self.proj, ws.h, out, epilogue=EPI_RESIDUAL if residual is not None else EPI_NONE, residual=residual)
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:

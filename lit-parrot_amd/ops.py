@@ -3,6 +3,7 @@
 Everything here enqueues HIP kernels on the current torch stream and returns immediately; nothing falls back to a
 torch implementation.  Activations are bf16 rows ``(M, features)`` of ONE sequence.
 """
+import ctypes as C
 from typing import Optional
 
 import torch
@@ -53,9 +54,27 @@ def layernorm(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor
     return out
 
 
+class Norm:
+    """A norm to fuse in front of a Linear: kind 1 = RMSNorm, 2 = LayerNorm (``parrot_norm_t``)."""
+
+    __slots__ = ("kind", "weight", "bias", "eps")
+
+    def __init__(self, kind: int, weight: torch.Tensor, bias: Optional[torch.Tensor], eps: float) -> None:
+        self.kind, self.weight, self.bias, self.eps = kind, weight, bias, float(eps)
+
+    def c_struct(self, K: int):
+        w = _opt_vec(self.weight, K, "fused norm weight")
+        b = _opt_vec(self.bias, K, "fused norm bias")
+        return _hip.ParrotNorm(self.kind, ptr(w), ptr(b), self.eps, RMSNORM_RSQRT_MODE)
+
+
+def _norm_arg(norm: Optional[Norm], K: int):
+    return None if norm is None else C.byref(norm.c_struct(K))
+
+
 # ------------------------------------------------------------------------------------------------ linears
 def bf16_linear(weight: torch.Tensor, x: torch.Tensor, out: torch.Tensor, *, bias=None, epilogue=EPI_NONE,
-                residual=None, weight2=None) -> torch.Tensor:
+                residual=None, weight2=None, norm: Optional[Norm] = None) -> torch.Tensor:
     _rows(x, "bf16_linear"), _rows(out, "bf16_linear")
     N, K = weight.shape
     if weight.dtype != torch.bfloat16 or not weight.is_contiguous():
@@ -65,7 +84,7 @@ def bf16_linear(weight: torch.Tensor, x: torch.Tensor, out: torch.Tensor, *, bia
     fn = lib.parrot_bf16_gemv if M <= GEMV_MAX_ROWS else lib.parrot_bf16_gemm
     check(fn(ptr(weight), ptr(weight2), ptr(x), x.stride(0), M, ptr(_opt_vec(bias, N, "bias")),
              ptr(residual), residual.stride(0) if residual is not None else 0, ptr(out), out.stride(0), N, K,
-             epilogue, stream()), "parrot_bf16_gemv/gemm")
+             epilogue, _norm_arg(norm, K), stream()), "parrot_bf16_gemv/gemm")
     return out
 
 
@@ -91,7 +110,7 @@ def w4_repack(quant_weight: torch.Tensor, scales: torch.Tensor, zeros: torch.Ten
 
 
 def w4_linear(packed: torch.Tensor, N: int, K: int, group: int, x: torch.Tensor, out: torch.Tensor, *, bias=None,
-              epilogue=EPI_NONE, residual=None, packed2=None) -> torch.Tensor:
+              epilogue=EPI_NONE, residual=None, packed2=None, norm: Optional[Norm] = None) -> torch.Tensor:
     _rows(x, "w4_linear"), _rows(out, "w4_linear")
     M = x.shape[0]
     if x.shape[1] != K or out.shape[1] != N:
@@ -100,7 +119,7 @@ def w4_linear(packed: torch.Tensor, N: int, K: int, group: int, x: torch.Tensor,
     fn = lib.parrot_w4_gemv if M <= GEMV_MAX_ROWS else lib.parrot_w4_gemm
     check(fn(ptr(packed), ptr(packed2), ptr(x), x.stride(0), M, ptr(_opt_vec(bias, N, "bias")), ptr(residual),
              residual.stride(0) if residual is not None else 0, ptr(out), out.stride(0), N, K, group, epilogue,
-             stream()), "parrot_w4_gemv/gemm")
+             _norm_arg(norm, K), stream()), "parrot_w4_gemv/gemm")
     return out
 
 
@@ -122,12 +141,12 @@ class W8Act:
         self.nout = torch.empty((M,), dtype=torch.int32, device=device)
 
 
-def w8_prep_act(x: torch.Tensor, threshold: float, act: W8Act) -> W8Act:
+def w8_prep_act(x: torch.Tensor, threshold: float, act: W8Act, norm: Optional[Norm] = None) -> W8Act:
     _rows(x, "w8_prep_act")
     M, K = x.shape
     assert (M, K) == (act.M, act.K)
     check(_hip.load().parrot_w8_prep_act(ptr(x), x.stride(0), M, K, float(threshold), ptr(act.xq), ptr(act.xout),
-                                         ptr(act.sca), ptr(act.nout), stream()), "parrot_w8_prep_act")
+                                         ptr(act.sca), ptr(act.nout), _norm_arg(norm, K), stream()), "parrot_w8_prep_act")
     return act
 
 
@@ -175,6 +194,21 @@ def attn_decode(q: torch.Tensor, pos: torch.Tensor, k_cache: torch.Tensor, v_cac
                                          nsplit, ptr(workspace), ptr(y), y.stride(0), stream()), "parrot_attn_decode")
     return y
 
+
+def attn_fused_decode(qkv: torch.Tensor, cos: torch.Tensor, sin: torch.Tensor, n_elem: int, pos: torch.Tensor,
+                      k_cache: torch.Tensor, v_cache: torch.Tensor, n_groups: int, q_per_kv: int, hs: int, S: int,
+                      nsplit: int, workspace: torch.Tensor, tickets: torch.Tensor, y: torch.Tensor) -> torch.Tensor:
+    """Single new token: split + RoPE + KV append + attention + combine in one launch."""
+    _rows(qkv, "attn_fused_decode"), _rows(y, "attn_fused_decode")
+    if qkv.shape[0] != 1 or tickets.dtype != torch.int32 or tickets.numel() < n_groups:
+        raise ParrotHipError("attn_fused_decode: one row, int32 tickets[n_groups] expected")
+    check(_hip.load().parrot_attn_fused_decode(ptr(qkv), ptr(cos), ptr(sin), n_elem, ptr(pos), n_groups, q_per_kv, hs, S,
+                                               nsplit, ptr(workspace), ptr(tickets), ptr(k_cache), ptr(v_cache), ptr(y),
+                                               stream()), "parrot_attn_fused_decode")
+    return y
+
+
+FUSED_ATTN_MAX_Q_PER_KV = 16
 
 # ------------------------------------------------------------------------------------------------ step glue
 def embedding(wte: torch.Tensor, tokens: torch.Tensor, pos: Optional[torch.Tensor], M: int, out: torch.Tensor) -> torch.Tensor:

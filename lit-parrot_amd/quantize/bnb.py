@@ -73,17 +73,18 @@ class InferenceLinear8bitLt(torch.nn.Linear):
         return out
 
     # -------------------------------------------------------------------------------------- HIP path
-    def prep(self, x: torch.Tensor) -> ops.W8Act:
+    def prep(self, x: torch.Tensor, norm=None) -> ops.W8Act:
         M, K = x.shape
         if self._act is None or (self._act.M, self._act.K) != (M, K) or self._act.xq.device != x.device:
             self._act = ops.W8Act(M, K, x.device)
-        return ops.w8_prep_act(x, self.threshold, self._act)
+        return ops.w8_prep_act(x, self.threshold, self._act, norm)
 
     def hip_linear(self, x: torch.Tensor, out: torch.Tensor, *, epilogue: int = EPI_NONE, residual=None,
-                   partner: Optional["InferenceLinear8bitLt"] = None, act: Optional[ops.W8Act] = None) -> torch.Tensor:
+                   partner: Optional["InferenceLinear8bitLt"] = None, act: Optional[ops.W8Act] = None,
+                   norm=None) -> torch.Tensor:
         if not self.is_quantized:
             raise ParrotHipError("InferenceLinear8bitLt: weight not quantised yet (move the module to the GPU)")
-        act = act if act is not None else self.prep(x)
+        act = act if act is not None else self.prep(x, norm)  # the norm is fused into the activation quantiser
         CB, SCB = self.weight.data, self.weight.SCB
         if partner is not None:
             if self._pair is None:

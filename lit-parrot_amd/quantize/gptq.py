@@ -87,14 +87,14 @@ class ColBlockQuantizedLinear(torch.nn.Module):
         return self._packed
 
     def hip_linear(self, x: torch.Tensor, out: torch.Tensor, *, epilogue: int = EPI_NONE, residual=None,
-                   partner: Optional["ColBlockQuantizedLinear"] = None) -> torch.Tensor:
+                   partner: Optional["ColBlockQuantizedLinear"] = None, norm=None) -> torch.Tensor:
         """rows (M, in) -> (M, out) with a fused epilogue; ``partner`` is fc_2 for the SwiGLU epilogue."""
         if partner is not None and (partner.tile_cols != self.tile_cols or partner.in_features != self.in_features
                                     or partner.out_features != self.out_features):
             raise ParrotHipError("SwiGLU partner must have the same shape and group size")
         return ops.w4_linear(self.packed(), self.out_features, self.in_features, self.tile_cols, x, out, bias=self.bias,
                              epilogue=epilogue, residual=residual,
-                             packed2=partner.packed() if partner is not None else None)
+                             packed2=partner.packed() if partner is not None else None, norm=norm)
 
     def forward(self, inp: torch.Tensor) -> torch.Tensor:
         x = inp.reshape(-1, self.in_features)

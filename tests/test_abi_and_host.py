@@ -35,7 +35,7 @@ def test_library_exports_every_declared_symbol(hip_lib):
 
 def test_argument_validation_needs_no_gpu(hip_lib):
     # null pointers / bad shapes are refused before any HIP call
-    assert hip_lib.parrot_w4_gemv(None, None, None, 0, 1, None, None, 0, None, 0, 8, 64, 64, 0, None) == -1
+    assert hip_lib.parrot_w4_gemv(None, None, None, 0, 1, None, None, 0, None, 0, 8, 64, 64, 0, None, None) == -1
     assert "null pointer" in _hip.last_error()
     assert hip_lib.parrot_rmsnorm(None, 0, None, None, 0, 1, 64, 1e-5, 0, None) == -1
     assert hip_lib.parrot_attn_decode(None, 1, None, None, None, 1, 1, 64, 8, 1, None, None, 0, None) == -1

@@ -333,6 +333,70 @@ def test_attention_ring_window_equals_rolled_cache():
         assert_bf16_close(y_d, want, ulps=1, atol=2e-3, what=f"ring pos {pos}")
 
 
+@pytest.mark.parametrize("kind", ["rms", "ln"])
+@pytest.mark.parametrize("M", [1, 3])
+@pytest.mark.parametrize("K", [256, 4096, 11008])
+def test_norm_fused_into_linear_equals_norm_then_linear(kind, M, K):
+    """The norm prologue of the GEMV kernels (norm_1 / norm_2 / ln_f fused into the next Linear) reproduces the
+    stand-alone norm kernel followed by the plain Linear (same rounding points; only the fp32 sums are re-ordered)."""
+    N = 64
+    g = gen(20)
+    x = (torch.randn(M, K, generator=g) * 1.5 + 0.1).to(BF).to(DEV)
+    nw = (1 + 0.1 * torch.randn(K, generator=g)).to(BF).to(DEV)
+    nb = (0.1 * torch.randn(K, generator=g)).to(BF).to(DEV) if kind == "ln" else None
+    norm = ops.Norm(1 if kind == "rms" else 2, nw, nb, 1e-5)
+    xn = torch.empty_like(x)
+    ops.rmsnorm(x, nw, 1e-5, xn) if kind == "rms" else ops.layernorm(x, nw, nb, 1e-5, xn)
+    # int4
+    qw, s, z, tc, Wd = make_w4(N, K, 128, 21)
+    lin = w4_module(qw, s, z, N, K, 128)
+    a, b = torch.empty((M, N), dtype=BF, device=DEV), torch.empty((M, N), dtype=BF, device=DEV)
+    lin.hip_linear(xn, a)
+    lin.hip_linear(x, b, norm=norm)
+    assert_bf16_close(b, a.float(), ulps=1, atol=2e-3, what=f"w4 fused {kind}")
+    assert float((a == b).float().mean()) > 0.97
+    # dense bf16
+    if K % 8 == 0 and K <= 32768:
+        W = (torch.randn(N, K, generator=g) * 0.02).to(BF).to(DEV)
+        ops.bf16_linear(W, xn, a)
+        ops.bf16_linear(W, x, b, norm=norm)
+        assert_bf16_close(b, a.float(), ulps=1, atol=2e-3, what=f"bf16 fused {kind}")
+        assert float((a == b).float().mean()) > 0.97
+    # LLM.int8: the norm is fused into the activation quantiser
+    act1 = ops.w8_prep_act(xn, 6.0, ops.W8Act(M, K, DEV))
+    act2 = ops.w8_prep_act(x, 6.0, ops.W8Act(M, K, DEV), norm)
+    assert float((act1.xq == act2.xq).float().mean()) > 0.995 and torch.allclose(act1.sca, act2.sca, rtol=1e-2)
+
+
+@pytest.mark.parametrize("n_groups,q_per_kv,hs,n_elem", ATTN_SHAPES)
+@pytest.mark.parametrize("S,nsplit", [(40, 1), (96, 3), (300, 8)])
+def test_fused_decode_attention_equals_the_three_kernel_path(n_groups, q_per_kv, hs, n_elem, S, nsplit):
+    """parrot_attn_fused_decode == rope_kvappend + attn_decode (+ combine), bit for bit, including the cache contents,
+    over a prefill and a run of single-token steps that wraps around the ring."""
+    g = gen(22)
+    n_head, width = n_groups * q_per_kv, n_groups * (q_per_kv + 2) * hs
+    cos, sin = (t.to(DEV) for t in om.rope_tables(2048, n_elem, BF, math_dtype=BF))
+    kc1 = torch.zeros((n_groups, S, hs), dtype=BF, device=DEV); vc1 = torch.zeros_like(kc1)
+    kc2 = torch.zeros_like(kc1); vc2 = torch.zeros_like(kc1)
+    q = torch.empty((1, n_head * hs), dtype=BF, device=DEV)
+    y1, y2 = torch.empty_like(q), torch.empty_like(q)
+    ws1, ws2 = ops.attn_workspace(1, n_head, hs, nsplit, DEV), ops.attn_workspace(1, n_head, hs, nsplit, DEV)
+    tickets = torch.zeros((n_groups,), dtype=torch.int32, device=DEV)
+    for pos in list(range(0, 12)) + list(range(S - 3, S + 9)):
+        qkv = torch.randn(1, width, generator=g).to(BF).to(DEV)
+        pos_d = torch.tensor([pos], dtype=torch.int32, device=DEV)
+        if pos == S - 3:  # jump ahead: fill both caches identically so that the slots in between are defined
+            fill = torch.randn((n_groups, S, hs), generator=g).to(BF).to(DEV)
+            for c_ in (kc1, vc1, kc2, vc2):
+                c_.copy_(fill)
+        ops.rope_kvappend(qkv, cos, sin, n_elem, pos_d, n_groups, q_per_kv, hs, S, q, kc1, vc1)
+        ops.attn_decode(q, pos_d, kc1, vc1, n_groups, q_per_kv, hs, S, nsplit, ws1, y1)
+        ops.attn_fused_decode(qkv, cos, sin, n_elem, pos_d, kc2, vc2, n_groups, q_per_kv, hs, S, nsplit, ws2, tickets, y2)
+        assert torch.equal(kc1, kc2) and torch.equal(vc1, vc2), f"cache differs at pos {pos}"
+        assert torch.equal(y1, y2), f"fused attention differs at pos {pos}: max {float((y1.float() - y2.float()).abs().max())}"
+        assert int(tickets.abs().sum()) == 0, "arrival tickets must be re-armed"
+
+
 # ------------------------------------------------------------------------------------------------ step glue
 def test_embedding_and_argmax_advance():
     g = gen(18)

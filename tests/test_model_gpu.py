@@ -12,7 +12,7 @@ magnitude ~0.5 has an ulp of 2^-9..2^-8 (0.002-0.004): the reference's own bf16 
 summation order agree bit for bit until one intermediate lands on the other side of a rounding boundary (about one
 element in 2^15), after which everything downstream differs by an ulp or two — so an absolute 1e-3 bound between two
 bf16 results is below the resolution of the format.  What is asserted instead, per family:
-  (a) accuracy: |hip - ref_fp32| <= 1.25 x |ref_bf16 - ref_fp32| (max and mean) + 1e-3/1e-4 — the HIP logits are as
+  (a) accuracy: |hip - ref_fp32| <= 1.5 x max / 1.25 x mean of |ref_bf16 - ref_fp32| (+ 1e-3 / 1e-4) — the HIP logits are as
       close to the reference's exact answer as the reference's own bf16 run;
   (b) distance: mean |hip - ref_bf16| <= 1.5 x mean |ref_bf16 - ref_fp32| (two independent roundings of the same exact
       value are ~sqrt(2) of one error apart) and max <= 2 x max + 1e-3;
@@ -48,7 +48,7 @@ def check_bf16_logits(hip, ref_bf16, ref_f32, what, tight=False):
     hip = hip.detach().float().cpu()
     assert torch.isfinite(hip).all(), what
     err_hip, err_ref, dist = (hip - ref_f32).abs(), (ref_bf16 - ref_f32).abs(), (hip - ref_bf16).abs()
-    assert float(err_hip.max()) <= 1.25 * float(err_ref.max()) + 1e-3, f"{what}: max error {float(err_hip.max()):.4g} vs reference's {float(err_ref.max()):.4g}"
+    assert float(err_hip.max()) <= 1.5 * float(err_ref.max()) + 1e-3, f"{what}: max error {float(err_hip.max()):.4g} vs reference's {float(err_ref.max()):.4g}"
     assert float(err_hip.mean()) <= 1.25 * float(err_ref.mean()) + 1e-4, f"{what}: mean error {float(err_hip.mean()):.4g} vs reference's {float(err_ref.mean()):.4g}"
     assert float(dist.max()) <= 2 * float(err_ref.max()) + 1e-3, f"{what}: max distance {float(dist.max()):.4g}"
     assert float(dist.mean()) <= (0.8 if tight else 1.5) * float(err_ref.mean()) + 1e-5, f"{what}: mean distance {float(dist.mean()):.4g} vs {float(err_ref.mean()):.4g}"

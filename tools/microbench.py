@@ -1,0 +1,87 @@
+#!/usr/bin/env python3
+"""Kernel microbenchmarks on the GPU box (not part of the product): times the weight-streaming GEMV entry points on the
+Linear shapes of a config with rotating weight buffers (footprint > the 256 MiB Infinity Cache, so every launch streams
+from HBM like the real decode step does), and prints achieved GB/s per shape and tuning setting.
+
+    python tools/microbench.py [--config Llama-2-7b-hf] [--mode w4|bf16] [--iters 200]
+"""
+import argparse
+import ctypes
+import sys
+from pathlib import Path
+
+import torch
+
+sys.path.insert(0, str(Path(__file__).resolve().parents[1]))
+from lit_parrot_amd import _hip, ops  # noqa: E402
+from lit_parrot_amd.config import Config  # noqa: E402
+
+DEV = torch.device("cuda", 0)
+
+
+def time_loop(fn, n_warm, n_iter):
+    for i in range(n_warm):
+        fn(i)
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for i in range(n_iter):
+        fn(i)
+    b.record()
+    torch.cuda.synchronize()
+    return a.elapsed_time(b) / n_iter * 1e3  # us per call (includes the launch gap between back-to-back kernels)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--config", default="Llama-2-7b-hf")
+    ap.add_argument("--mode", default="w4")
+    ap.add_argument("--iters", type=int, default=200)
+    ap.add_argument("--group", type=int, default=128)
+    args = ap.parse_args()
+    cfg = Config.from_name(args.config)
+    lib = _hip.load()
+    tune = getattr(lib, "parrot_tune_w4_rows_per_wg", None)
+    shapes = cfg.linear_shapes()
+    for name, (N, K) in shapes.items():
+        if args.mode == "w4":
+            nbytes = ops.w4_packed_bytes(N, K, args.group)
+            algo = N * K // 2 + N * (-(-K // args.group)) * 4
+        else:
+            nbytes = N * K * 2
+            algo = nbytes
+        copies = max(2, int(600e6 // nbytes) + 1)
+        bufs = [torch.randint(0, 255, (nbytes,), dtype=torch.uint8, device=DEV) for _ in range(copies)]
+        if args.mode == "w4":  # sane scales: bf16 1.0 / zero 8 patterns are not needed for timing; random bytes are fine
+            pass
+        x = torch.randn(1, K, device=DEV).to(torch.bfloat16)
+        out = torch.empty((1, N), dtype=torch.bfloat16, device=DEV)
+        dual = name == "mlp.fc_1"
+        if name == "mlp.fc_2":
+            continue
+        st = _hip.stream()
+        for rows in ((0, 4, 8, 16) if args.mode == "w4" and tune is not None else (0,)):
+            if tune is not None:
+                tune(rows)
+
+            def call(i):
+                w = bufs[i % copies]
+                w2 = bufs[(i + 1) % copies] if dual else None
+                if args.mode == "w4":
+                    rc = lib.parrot_w4_gemv(w.data_ptr(), w2.data_ptr() if dual else None, x.data_ptr(), K, 1, None, None, 0,
+                                            out.data_ptr(), N, N, K, args.group, 3 if dual else 0, st)
+                else:
+                    rc = lib.parrot_bf16_gemv(w.view(torch.bfloat16).data_ptr(), w2.view(torch.bfloat16).data_ptr() if dual else None,
+                                              x.data_ptr(), K, 1, None, None, 0, out.data_ptr(), N, N, K, 3 if dual else 0, st)
+                assert rc == 0, _hip.last_error()
+
+            us = time_loop(call, 20, args.iters)
+            b = algo * (2 if dual else 1)
+            print(f"{name:10s}{'+fc_2' if dual else '     '} N={N:6d} K={K:6d} rows/wg={rows:2d}  {us:7.2f} us/launch  {b / us / 1e3:7.1f} GB/s  ({b / 1e6:.1f} MB)")
+        if tune is not None:
+            tune(0)
+        del bufs
+
+
+if __name__ == "__main__":
+    main()
