@@ -82,6 +82,29 @@ def kernel_bytes_per_token(cfg, mode):
     return res  # {kernel name: (bytes per token, launches per token)}
 
 
+PMC_KERNEL_PREFIX = {"w4_gemv": "w4_gemv_kernel<1, false", "w4_gemv_dual": "w4_gemv_kernel<1, true",
+                     "bf16_gemv": "bf16_gemv_kernel<1, false", "bf16_gemv_dual": "bf16_gemv_kernel<1, true",
+                     "w8_gemv": "w8_gemv_kernel", "attn_fused_decode": "attn_fused_decode_kernel"}
+
+
+def pmc_traffic(kernel: str):
+    """HBM bytes per launch of ``kernel`` from the newest committed PMC summary (profiles/*_pmc_traffic.json, written by
+    tools/summarize_profiles.py from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this benchmark).
+    Counters cannot be collected inside the timed run; returns (bytes per launch or None, source file)."""
+    files = sorted((REPO / "profiles").glob("*_pmc_traffic.json"))
+    prefix = PMC_KERNEL_PREFIX.get(kernel)
+    if not files or prefix is None:
+        return None, None
+    entries = json.loads(files[-1].read_text())["kernels"]
+    tot_b = tot_n = 0.0
+    for name, v in entries.items():
+        if name.startswith(prefix) and "hbm_bytes_per_launch_corrected" in v:
+            n = v.get("launches_FETCH_SIZE", 1)
+            tot_b += v["hbm_bytes_per_launch_corrected"] * n
+            tot_n += n
+    return (tot_b / tot_n if tot_n else None), files[-1].name
+
+
 def rank_env():
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
@@ -217,8 +240,10 @@ def main() -> None:
         bytes_per_launch = kb[dom][0] / kb[dom][1]
         avg_s = stats[dom][0] / stats[dom][1] * 1e-3
         achieved = bytes_per_launch / avg_s / 1e9
+        traffic, traffic_src = pmc_traffic(dom) if args.workload == "llama2-7b-int4" else (None, None)
         roofline = {"kernel": dom, "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": achieved / HBM_PEAK_GBS, "traffic": None, "bytes_per_launch": bytes_per_launch,
+                    "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+                    "bytes_per_launch": bytes_per_launch,
                     "avg_launch_us": avg_s * 1e6, "launches_per_token": kb[dom][1]}
     step_gbs = (w_bytes + kv_bytes) / (ms_per_step * 1e-3) / 1e9
 

@@ -253,22 +253,54 @@ attn_fused_decode_kernel(const bf16_t* __restrict__ qkv, const __half* __restric
     const float scale = 1.0f / sqrtf((float)HS);
     const int half_n = n_elem >> 1;
 
-    // ---- split + RoPE of this group's rows (reference model.py:208-232)
+    const uint4* kc = reinterpret_cast<const uint4*>(k_cache + (int64_t)g * S * HS);
+    const uint4* vc = reinterpret_cast<const uint4*>(v_cache + (int64_t)g * S * HS);
+    const int slot = wave * RPW + sub;
+    constexpr int STRIDE = kAttnWaves * RPW;
+    // Load order matters (vmcnt retires in order): first the small L2-resident operands of the RoPE phase (this
+    // group's q/k/v rows, cos/sin), then the first K/V rows of this wave, which do not depend on q — their HBM latency
+    // overlaps the split + RoPE phase.  (Rows past the range are clamped; the appended row is replaced later.)
+    constexpr int ROPE_IT = ((kFusedMaxQ + 2) * HS + kAttnWaves * 64 - 1) / (kAttnWaves * 64);
     const bf16_t* grp = qkv + (int64_t)g * (q_per_kv + 2) * HS;
-    for (int idx = threadIdx.x; idx < (q_per_kv + 2) * HS; idx += kAttnWaves * 64) {
-        const int t = idx / HS, d = idx % HS;
-        float v = bf2f(grp[idx]);
-        if (t <= q_per_kv && d < n_elem) {
-            const float c = __half2float(rope_cos[(int64_t)pos * n_elem + d]);
-            const float sn = __half2float(rope_sin[(int64_t)pos * n_elem + d]);
-            const float other = d < half_n ? -bf2f(grp[idx + half_n]) : bf2f(grp[idx - half_n]);
-            v = __fadd_rn(__fmul_rn(v, c), __fmul_rn(other, sn));
+    const int n_rope_elems = (q_per_kv + 2) * HS;
+    float rx[ROPE_IT], ro[ROPE_IT], rc[ROPE_IT], rs[ROPE_IT];
+#pragma unroll
+    for (int it = 0; it < ROPE_IT; ++it) {
+        const int idx = threadIdx.x + it * kAttnWaves * 64;
+        rx[it] = ro[it] = rs[it] = 0.f;
+        rc[it] = 1.f;
+        if (idx < n_rope_elems) {
+            const int t = idx / HS, d = idx % HS;
+            rx[it] = bf2f(grp[idx]);
+            if (t <= q_per_kv && d < n_elem) {
+                rc[it] = __half2float(rope_cos[(int64_t)pos * n_elem + d]);
+                rs[it] = __half2float(rope_sin[(int64_t)pos * n_elem + d]);
+                ro[it] = d < half_n ? -bf2f(grp[idx + half_n]) : bf2f(grp[idx - half_n]);
+            }
         }
-        const bf16_t vb = f2bf(v);
-        if (t < q_per_kv)
-            sh_q[t][d] = bf2f(vb) * scale;
-        else
-            sh_kv[t - q_per_kv][d] = vb;
+    }
+    const int s_first = s_begin + wave * RPW;
+    uint4 kv_cur = make_uint4(0, 0, 0, 0), vv_cur = kv_cur;
+    if (s_first < s_end) {
+        const int sc = min(s_first + sub, s_end - 1);
+        kv_cur = kc[(int64_t)sc * LPR + dl];
+        vv_cur = vc[(int64_t)sc * LPR + dl];
+    }
+
+    // ---- split + RoPE of this group's rows (reference model.py:208-232): x*cos + rotate_half(x)*sin, each product and
+    // the sum rounded to fp32 separately; elements outside the rotary part pass through (cos = 1, sin = 0 is exact)
+#pragma unroll
+    for (int it = 0; it < ROPE_IT; ++it) {
+        const int idx = threadIdx.x + it * kAttnWaves * 64;
+        if (idx < n_rope_elems) {
+            const int t = idx / HS, d = idx % HS;
+            const float v = __fadd_rn(__fmul_rn(rx[it], rc[it]), __fmul_rn(ro[it], rs[it]));
+            const bf16_t vb = f2bf(v);
+            if (t < q_per_kv)
+                sh_q[t][d] = bf2f(vb) * scale;
+            else
+                sh_kv[t - q_per_kv][d] = vb;
+        }
     }
     __syncthreads();
     // ---- KV append by the workgroup that owns the new slot
@@ -279,9 +311,6 @@ attn_fused_decode_kernel(const bf16_t* __restrict__ qkv, const __half* __restric
     }
     const uint4 knew = reinterpret_cast<const uint4*>(sh_kv[0])[dl];
     const uint4 vnew = reinterpret_cast<const uint4*>(sh_kv[1])[dl];
-    const uint4* kc = reinterpret_cast<const uint4*>(k_cache + (int64_t)g * S * HS);
-    const uint4* vc = reinterpret_cast<const uint4*>(v_cache + (int64_t)g * S * HS);
-    const int slot = wave * RPW + sub;
 
     for (int h0 = 0; h0 < q_per_kv; h0 += HQ) {
         float qf[HQ][8];
@@ -296,12 +325,23 @@ attn_fused_decode_kernel(const bf16_t* __restrict__ qkv, const __half* __restric
 #pragma unroll
             for (int e = 0; e < 8; ++e) acc[hh][e] = 0.f;
         }
-        for (int s0 = s_begin + wave * RPW; s0 < s_end; s0 += kAttnWaves * RPW) {
+        if (h0 != 0 && s_first < s_end) {  // later head passes (GQA) re-read the rows, now from L2
+            const int sc = min(s_first + sub, s_end - 1);
+            kv_cur = kc[(int64_t)sc * LPR + dl];
+            vv_cur = vc[(int64_t)sc * LPR + dl];
+        }
+        for (int s0 = s_first; s0 < s_end; s0 += STRIDE) {
+            // software pipeline: request the next rows before working on the current ones
+            uint4 kv_nxt = kv_cur, vv_nxt = vv_cur;
+            if (s0 + STRIDE < s_end) {
+                const int sn = min(s0 + STRIDE + sub, s_end - 1);
+                kv_nxt = kc[(int64_t)sn * LPR + dl];
+                vv_nxt = vc[(int64_t)sn * LPR + dl];
+            }
             const int s = s0 + sub;
             const bool ok = s < s_end;
             const int sc = ok ? s : s_end - 1;
-            uint4 kv = kc[(int64_t)sc * LPR + dl];
-            uint4 vv = vc[(int64_t)sc * LPR + dl];
+            uint4 kv = kv_cur, vv = vv_cur;
             if (sc == slot_new) {  // the row being appended by this launch: use the in-register copy
                 kv = knew;
                 vv = vnew;
@@ -333,6 +373,8 @@ attn_fused_decode_kernel(const bf16_t* __restrict__ qkv, const __half* __restric
                     mrun[hh] = mn;
                 }
             }
+            kv_cur = kv_nxt;
+            vv_cur = vv_nxt;
         }
         __syncthreads();
 #pragma unroll

@@ -144,7 +144,6 @@ w4_repack_kernel(uint8_t* __restrict__ qref, bf16_t* __restrict__ scales, bf16_t
 }
 
 // ------------------------------------------------------------------------------------------ GEMV
-constexpr int kU = 8;         // rows in flight per wave per iteration (all loads issued before the first use)
 constexpr int kMaxRows = 16;  // rows per workgroup
 
 __device__ __forceinline__ float w4_slice_dot(const uint4 w, const uint32_t (&xr)[16]) {
@@ -164,8 +163,10 @@ __device__ __forceinline__ float w4_slice_dot(const uint4 w, const uint32_t (&xr
     return p0 + p1;
 }
 
-template <int M, bool DUAL>
-__global__ void __launch_bounds__(1024)
+// RU = rows whose loads are in flight together per wave; MAXW = waves per workgroup the build allows (the register budget
+// follows from it: 8 waves -> 256 VGPRs, 16 waves -> 128)
+template <int M, bool DUAL, int RU, int MAXW>
+__global__ void __launch_bounds__(MAXW * 64)
 w4_gemv_kernel(const uint4* __restrict__ W, const uint4* __restrict__ W2, const bf16_t* __restrict__ x, int ldx,
                const bf16_t* __restrict__ bias, const bf16_t* residual, int ldr, bf16_t* out, int ldo, int N,
                int rows_per_wg, int epi, NormArgs na, W4Plan plan) {
@@ -184,6 +185,7 @@ w4_gemv_kernel(const uint4* __restrict__ W, const uint4* __restrict__ W2, const 
     const int r_begin = blockIdx.x * rows_per_wg;
     const int r_end = min(N, r_begin + rows_per_wg);
 
+    constexpr int kU = RU;
     uint4 w[NW][kU];
     uint32_t mt[NW][kU];
     // All kU row loads of a batch are issued back to back before anything waits.  Weights are read exactly once per
@@ -200,10 +202,9 @@ w4_gemv_kernel(const uint4* __restrict__ W, const uint4* __restrict__ W2, const 
             mt[1][u] = load_nt4(reinterpret_cast<const uint32_t*>(rec2 + sl.meta_off16) + gl);       \
         }                                                                                            \
     }
-    // the first batch of weights is requested BEFORE the activations: the HBM stream starts at once and the
-    // (L2-resident) activation loads and the norm prologue run under its latency
-    W4_LOAD_BATCH(r_begin)
-
+    // Load order matters because vmcnt retires in order: first the small L2-resident operands (activations, norm
+    // parameters), then the first batch of weights.  The norm prologue then only waits for the former while the
+    // HBM stream of the latter is already running.
     // this lane's 32 activations per row of x, as 16 packed bf16 pairs
     uint32_t xr[M][16];
     float xs[M];
@@ -220,20 +221,22 @@ w4_gemv_kernel(const uint4* __restrict__ W, const uint4* __restrict__ W2, const 
             xr[m][4 * j + 3] = v.w;
         }
     }
-    if (na.kind != 0) {  // fused RMSNorm / LayerNorm of the input rows (wave-uniform branch)
-        uint32_t nw[16], nb[16];
-        {
-            const uint4* wp = reinterpret_cast<const uint4*>(na.weight + (int64_t)gslice * 32);
-            const uint4* bp = reinterpret_cast<const uint4*>(na.bias + (int64_t)gslice * 32);
+    uint32_t nw[16], nb[16];
+    if (na.kind != 0) {
+        const uint4* wp = reinterpret_cast<const uint4*>(na.weight + (int64_t)gslice * 32);
+        const uint4* bp = reinterpret_cast<const uint4*>(na.bias + (int64_t)gslice * 32);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const uint4 v = wp[j];
-                nw[4 * j] = v.x; nw[4 * j + 1] = v.y; nw[4 * j + 2] = v.z; nw[4 * j + 3] = v.w;
-                uint4 b = make_uint4(0, 0, 0, 0);
-                if (na.kind == 2 && na.bias != nullptr) b = bp[j];
-                nb[4 * j] = b.x; nb[4 * j + 1] = b.y; nb[4 * j + 2] = b.z; nb[4 * j + 3] = b.w;
-            }
+        for (int j = 0; j < 4; ++j) {
+            const uint4 v = wp[j];
+            nw[4 * j] = v.x; nw[4 * j + 1] = v.y; nw[4 * j + 2] = v.z; nw[4 * j + 3] = v.w;
+            uint4 b = make_uint4(0, 0, 0, 0);
+            if (na.kind == 2 && na.bias != nullptr) b = bp[j];
+            nb[4 * j] = b.x; nb[4 * j + 1] = b.y; nb[4 * j + 2] = b.z; nb[4 * j + 3] = b.w;
         }
+    }
+    W4_LOAD_BATCH(r_begin)
+
+    if (na.kind != 0) {  // fused RMSNorm / LayerNorm of the input rows (wave-uniform branch)
 #pragma unroll
         for (int m = 0; m < M; ++m) {
             float s1 = 0.f;
@@ -306,19 +309,34 @@ static int pick_rows_per_wg(int N) {
     return 8;
 }
 
+template <int M, bool DUAL, int RU, int MAXW>
+static int w4_gemv_launch_v(const void* packed, const void* packed2, const void* x, int ldx, const void* bias,
+                            const void* residual, int ldr, void* out, int ldo, int N, int epi, const NormArgs& na,
+                            const W4Plan& plan, hipStream_t st) {
+    int R = pick_rows_per_wg(N);
+    if (R < RU) R = RU;
+    const dim3 grid((N + R - 1) / R), block(64 * plan.nslabs);
+    return launch(DUAL ? K_W4_GEMV_DUAL : K_W4_GEMV, w4_gemv_kernel<M, DUAL, RU, MAXW>, grid, block, 0, st,
+                  (const uint4*)packed, (const uint4*)packed2, (const bf16_t*)x, ldx, (const bf16_t*)bias,
+                  (const bf16_t*)residual, ldr, (bf16_t*)out, ldo, N, R, epi, na, plan);
+}
+
 template <int M>
 static int w4_gemv_launch(const void* packed, const void* packed2, const void* x, int ldx, const void* bias,
                           const void* residual, int ldr, void* out, int ldo, int N, int epi, const NormArgs& na,
                           const W4Plan& plan, hipStream_t st) {
-    const int R = pick_rows_per_wg(N);
-    const dim3 grid((N + R - 1) / R), block(64 * plan.nslabs);
-    if (epi == PARROT_EPI_SWIGLU)
-        return launch(K_W4_GEMV_DUAL, w4_gemv_kernel<M, true>, grid, block, 0, st, (const uint4*)packed,
-                      (const uint4*)packed2, (const bf16_t*)x, ldx, (const bf16_t*)bias, (const bf16_t*)residual, ldr,
-                      (bf16_t*)out, ldo, N, R, epi, na, plan);
-    return launch(K_W4_GEMV, w4_gemv_kernel<M, false>, grid, block, 0, st, (const uint4*)packed, (const uint4*)packed2,
-                  (const bf16_t*)x, ldx, (const bf16_t*)bias, (const bf16_t*)residual, ldr, (bf16_t*)out, ldo, N, R, epi,
-                  na, plan);
+    // rows in flight: 8 for the single-row decode kernel, 4 when a second weight or more rows share the registers
+    constexpr int RU1 = (M == 1) ? 8 : 4;
+    constexpr int RU2 = (M <= 2) ? 4 : 2;
+#define PARROT_W4_GO(DUALV, RUV, MAXWV) \
+    return w4_gemv_launch_v<M, DUALV, RUV, MAXWV>(packed, packed2, x, ldx, bias, residual, ldr, out, ldo, N, epi, na, plan, st)
+    if (plan.nslabs <= 8) {
+        if (epi == PARROT_EPI_SWIGLU) PARROT_W4_GO(true, RU2, 8);
+        PARROT_W4_GO(false, RU1, 8);
+    }
+    if (epi == PARROT_EPI_SWIGLU) PARROT_W4_GO(true, 2, 16);
+    PARROT_W4_GO(false, 4, 16);
+#undef PARROT_W4_GO
 }
 
 }  // namespace parrot

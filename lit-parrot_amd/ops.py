@@ -177,8 +177,9 @@ def rope_kvappend(qkv: torch.Tensor, cos: torch.Tensor, sin: torch.Tensor, n_ele
 
 
 def attn_nsplit(n_groups: int, S: int) -> int:
-    """Sequence splits of the decode-attention kernel: enough workgroups to cover the chip, >= 64 keys each."""
-    return max(1, min(S // 64, max(1, 512 // n_groups), 32))
+    """Sequence splits of the decode-attention kernel: about 32 keys per workgroup (two row batches per wave at
+    head size 128), bounded by ~1024 workgroups per launch and 64 splits."""
+    return max(1, min(S // 32, max(1, 1024 // n_groups), 64))
 
 
 def attn_workspace(M: int, n_head: int, hs: int, nsplit: int, device) -> torch.Tensor:
