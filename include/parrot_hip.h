@@ -153,6 +153,70 @@ int parrot_embedding(const void* wte, int d, const int64_t* tokens, const int32_
  * tokens[*pos + 1] = argmax(logits) (lowest index on ties); then *pos += 1.          */
 int parrot_argmax_advance(const void* logits, int V, int64_t* tokens, int32_t* pos, void* stream);
 
+/* ---- persistent decode step: ONE launch per token --------------------------------------------------
+ * The whole token (generate/base.py:131-153 for one iteration: embedding, every Block, ln_f, lm_head, greedy
+ * sampling) is a static program of ops run by 256 resident workgroups that hand activations over through
+ * write-through stores and arrival counters, so that the weight stream of op k+1 is already in flight while
+ * op k's results are exchanged (csrc/persist.hip).  The caller builds the program once per model (host array of
+ * parrot_pk_op_t, then copied to device memory) and calls parrot_pk_step per token; every pointer inside the
+ * structs is a device pointer owned by the caller.                                                          */
+#define PARROT_PK_GEMV 0   /* int4 Linear (W4K weights) with optional norm prologue and epilogue */
+#define PARROT_PK_ATTN 1   /* split + RoPE + KV append + attention + combine (x = QKV vector, out = heads) */
+#define PARROT_PK_ARGMAX 2 /* tokens[pos+1] = argmax(logits), pos += 1 */
+#define PARROT_PK_MAX_SLABS 12
+
+typedef struct parrot_pk_slab {
+    int32_t slice0, nslices, g0, w_off16, meta_off16;
+} parrot_pk_slab_t;
+
+typedef struct parrot_pk_op {
+    int32_t type;     /* PARROT_PK_* */
+    int32_t epilogue; /* PARROT_EPI_* */
+    int32_t N, K;
+    int32_t nslabs, row16, Gs; /* W4K plan, filled by parrot_pk_fill_w4 */
+    int32_t norm_kind;         /* 0 none, 1 RMSNorm, 2 LayerNorm fused in front */
+    float norm_eps;
+    int32_t x_from_embedding;   /* the input vector is wte[tokens[pos]] (first block) */
+    int32_t res_from_embedding; /* the residual is wte[tokens[pos]] (first block) */
+    int32_t track_argmax;       /* lm_head: also record this workgroup's arg-max */
+    const void* W;              /* W4K weights; W2 = second weight of the SwiGLU epilogue or NULL */
+    const void* W2;
+    const void* x;        /* input vector: K bf16 (GEMV) / the QKV vector (ATTN) */
+    const void* norm_w;   /* K bf16 */
+    const void* norm_b;   /* K bf16 or NULL */
+    const void* bias;     /* N bf16 or NULL */
+    const void* residual; /* N bf16 or NULL */
+    void* out;            /* N bf16 */
+    void* k_cache;        /* ATTN: [n_groups][S][hs] bf16 */
+    void* v_cache;
+    parrot_pk_slab_t slab[PARROT_PK_MAX_SLABS];
+} parrot_pk_op_t;
+
+typedef struct parrot_pk_state {
+    const parrot_pk_op_t* ops; /* device array */
+    int32_t nops;
+    int32_t d; /* n_embd */
+    int64_t* tokens;
+    int32_t* pos;
+    const void* wte;
+    const void* rope_cos;
+    const void* rope_sin;
+    int32_t n_elem, n_groups, q_per_kv, hs, S, V, rsqrt_mode;
+    int32_t lds_x_bytes; /* max over GEMV ops of 2*K, rounded up to 16 */
+    float* attn_ws;      /* parrot_attn_workspace_floats(1, n_head, hs, 256 / n_groups) */
+    uint32_t* tickets;   /* n_groups, zero-initialised */
+    uint32_t* counters;  /* 8 * 32 uint32 (8 shards on separate 128-B lines); zeroed by every parrot_pk_step */
+    uint32_t* err;       /* 1 word, zero-initialised; non-zero after a barrier timeout */
+    float* argmax_val;   /* 256 */
+    uint32_t* argmax_idx; /* 256 */
+    uint64_t* dbg;        /* NULL, or nops*8 words: 100 MHz timestamps of workgroup 0's phases (diagnostic runs only) */
+} parrot_pk_state_t;
+
+/* fill N, K and the W4K plan of a GEMV op (host side); PARROT_EUNSUPPORTED if the shape does not fit the step */
+int parrot_pk_fill_w4(parrot_pk_op_t* op_host, int N, int K, int group);
+/* one token: memset of the counters + the persistent kernel, enqueued on `stream` (graph-capturable) */
+int parrot_pk_step(const parrot_pk_state_t* state_host, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -65,6 +65,7 @@ enum KernelId : int {
     K_W4_GEMM,
     K_BF16_GEMM,
     K_ATTN_FUSED,
+    K_PK_TOKEN,
     K_COUNT
 };
 

@@ -1,0 +1,80 @@
+// W4K layout plan (shared by w4.hip and persist.hip): how the K axis of an int4 matrix is cut into per-wave slabs.
+#pragma once
+#include "parrot_common.h"
+
+namespace parrot {
+
+constexpr int kMaxSlabs = 16;
+
+struct W4Slab {
+    int slice0;      // first slice (32-k unit) of the slab
+    int nslices;     // <= 64
+    int g0;          // first group overlapping the slab
+    int ngroups;     // groups overlapping the slab
+    int w_off16;     // offset of the slab's weight slices inside a row record, in 16-B units
+    int meta_off16;  // offset of the slab's meta block inside a row record, in 16-B units
+};
+
+struct W4Plan {
+    int nslabs;
+    int row16;  // row record size in 16-B units
+    int Gs;     // slices per group
+    int nslices;
+    int ngroups;
+    W4Slab slab[kMaxSlabs];
+};
+
+inline int w4_make_plan(int N, int K, int group, W4Plan* p) {
+    PARROT_REQUIRE(N > 0 && K > 0, "w4: N and K must be positive (N=%d K=%d)", N, K);
+    PARROT_UNSUPPORTED(K % 32 == 0, "w4: K=%d must be a multiple of 32", K);
+    if (group <= 0 || group > K) group = K;  // tile_cols = -1 -> per-channel (quantize/gptq.py:210)
+    PARROT_UNSUPPORTED(group % 32 == 0, "w4: group size %d must be a multiple of 32", group);
+    const int nslices = K / 32;
+    const int Gs = group / 32;
+    const int unit = Gs <= 64 ? Gs : 1;  // slab boundaries fall on group starts when a group fits a slab
+    const int units = (nslices + unit - 1) / unit;
+    int nslabs = (nslices + 63) / 64;
+    while (nslabs <= kMaxSlabs && ((units + nslabs - 1) / nslabs) * unit > 64) ++nslabs;
+    PARROT_UNSUPPORTED(nslabs <= kMaxSlabs, "w4: K=%d group=%d needs more than %d slabs", K, group, kMaxSlabs);
+    p->nslabs = nslabs;
+    p->Gs = Gs;
+    p->nslices = nslices;
+    p->ngroups = (nslices + Gs - 1) / Gs;
+    int off = 0;
+    for (int c = 0; c < nslabs; ++c) {
+        const int u0 = (int)((int64_t)c * units / nslabs), u1 = (int)((int64_t)(c + 1) * units / nslabs);
+        W4Slab& s = p->slab[c];
+        s.slice0 = u0 * unit;
+        const int slice1 = (u1 * unit < nslices) ? u1 * unit : nslices;
+        s.nslices = slice1 - s.slice0;
+        s.g0 = s.slice0 / Gs;
+        s.ngroups = (slice1 - 1) / Gs - s.g0 + 1;
+        s.w_off16 = off;
+        off += s.nslices;
+        s.meta_off16 = off;
+        off += (s.ngroups * 4 + 15) / 16;
+    }
+    for (int c = nslabs; c < kMaxSlabs; ++c) p->slab[c] = W4Slab{0, 0, 0, 0, 0, 0};
+    p->row16 = off;
+    return PARROT_OK;
+}
+
+// fp32 sum over one 16-byte slice (32 weights) of x[k] * (128 + q[k]); xr = the lane's 16 packed bf16 activation pairs
+__device__ __forceinline__ float w4_slice_dot(const uint4 w, const uint32_t (&xr)[16]) {
+    const uint32_t dw[4] = {w.x, w.y, w.z, w.w};
+    float p0 = 0.f, p1 = 0.f;
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const uint32_t pk = ((dw[d] >> (4 * i)) & 0x000F000Fu) | 0x43004300u;
+            if (i & 1)
+                p1 = dot2_bf16(pk, xr[4 * d + i], p1);
+            else
+                p0 = dot2_bf16(pk, xr[4 * d + i], p0);
+        }
+    }
+    return p0 + p1;
+}
+
+}  // namespace parrot
