@@ -78,10 +78,14 @@ int parrot_w4_repack(void* quant_weight_ref, void* scales, void* zeros, int N, i
 int parrot_w4_gemv(const void* packed, const void* packed2, const void* x, int ldx, int M,
                    const void* bias, const void* residual, int ldr, void* out, int ldo, int N,
                    int K, int group, int epilogue, const parrot_norm_t* norm, void* stream);
-/* same contract for any M (prefill): MFMA path, dequant-to-LDS */
+/* same contract for any M (prefill) on the matrix cores (v_mfma_f32_32x32x16_bf16; the int4 rows are expanded to
+ * bf16 in LDS).  M <= 8 forwards to the GEMV.  For M > 8 the norm must already be applied (norm == NULL) and
+ * `workspace` holds parrot_gemm_workspace_floats(M, K, group) floats (per-group activation sums).            */
+int64_t parrot_gemm_workspace_floats(int M, int K, int group);
 int parrot_w4_gemm(const void* packed, const void* packed2, const void* x, int ldx, int M,
                    const void* bias, const void* residual, int ldr, void* out, int ldo, int N,
-                   int K, int group, int epilogue, const parrot_norm_t* norm, void* stream);
+                   int K, int group, int epilogue, const parrot_norm_t* norm, void* workspace,
+                   void* stream);
 
 /* ---- dense bf16 Linear (torch.nn.Linear on the bf16 path, lit_gpt/model.py:29,188,190,281-295)
  * W is (N, K) row-major bf16.                                                    */

@@ -30,6 +30,37 @@ class ParrotNorm(C.Structure):
 
 _np = C.POINTER(ParrotNorm)
 
+# ---- persistent decode step (parrot_pk_op_t / parrot_pk_state_t of include/parrot_hip.h)
+PK_GEMV, PK_ATTN, PK_ARGMAX = 0, 1, 2
+PK_MAX_SLABS = 12
+PK_WGS = 256
+
+
+class PkSlab(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("slice0", "nslices", "g0", "w_off16", "meta_off16")]
+
+
+class PkOp(C.Structure):  # parrot_pk_op_t
+    _fields_ = (
+        [(n, C.c_int32) for n in ("type", "epilogue", "N", "K", "nslabs", "row16", "Gs", "norm_kind")]
+        + [("norm_eps", C.c_float)]
+        + [(n, C.c_int32) for n in ("x_from_embedding", "res_from_embedding", "track_argmax")]
+        + [(n, C.c_void_p) for n in ("W", "W2", "x", "norm_w", "norm_b", "bias", "residual", "out", "k_cache", "v_cache")]
+        + [("slab", PkSlab * PK_MAX_SLABS)]
+    )
+
+
+class PkState(C.Structure):  # parrot_pk_state_t
+    _fields_ = (
+        [("ops", C.c_void_p), ("nops", C.c_int32), ("d", C.c_int32)]
+        + [(n, C.c_void_p) for n in ("tokens", "pos", "wte", "rope_cos", "rope_sin")]
+        + [(n, C.c_int32) for n in ("n_elem", "n_groups", "q_per_kv", "hs", "S", "V", "rsqrt_mode", "lds_x_bytes")]
+        + [(n, C.c_void_p) for n in ("attn_ws", "tickets", "counters", "err", "argmax_val", "argmax_idx", "dbg")]
+    )
+
+
+
+
 # name -> (restype, argtypes); must list every function include/parrot_hip.h declares
 SIGNATURES = {
     "parrot_version": (_i, []),
@@ -40,7 +71,8 @@ SIGNATURES = {
     "parrot_w4_packed_bytes": (_i64, [_i, _i, _i]),
     "parrot_w4_repack": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _i, _vp]),
     "parrot_w4_gemv": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _np, _vp]),
-    "parrot_w4_gemm": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _np, _vp]),
+    "parrot_gemm_workspace_floats": (_i64, [_i, _i, _i]),
+    "parrot_w4_gemm": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _np, _vp, _vp]),
     "parrot_bf16_gemv": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp, _i, _vp, _i, _i, _i, _i, _np, _vp]),
     "parrot_bf16_gemm": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp, _i, _vp, _i, _i, _i, _i, _np, _vp]),
     "parrot_w8_quantize_rows": (_i, [_vp, _i, _i, _vp, _vp, _vp]),
@@ -52,6 +84,8 @@ SIGNATURES = {
     "parrot_attn_workspace_floats": (_i64, [_i, _i, _i, _i]),
     "parrot_attn_decode": (_i, [_vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _i, _vp]),
     "parrot_attn_fused_decode": (_i, [_vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "parrot_pk_fill_w4": (_i, [C.POINTER(PkOp), _i, _i, _i]),
+    "parrot_pk_step": (_i, [C.POINTER(PkState), _vp]),
     "parrot_embedding": (_i, [_vp, _i, _vp, _vp, _i, _vp, _i, _vp]),
     "parrot_argmax_advance": (_i, [_vp, _i, _vp, _vp, _vp]),
 }

@@ -193,11 +193,4 @@ int parrot_bf16_gemv(const void* W, const void* W2, const void* x, int ldx, int 
     return PARROT_OK;
 }
 
-// Prefill entry point.  Round 1: row pairs through the GEMV kernel; the MFMA kernel replaces this body.
-int parrot_bf16_gemm(const void* W, const void* W2, const void* x, int ldx, int M, const void* bias,
-                     const void* residual, int ldr, void* out, int ldo, int N, int K, int epilogue,
-                     const parrot_norm_t* norm, void* stream) {
-    return parrot_bf16_gemv(W, W2, x, ldx, M, bias, residual, ldr, out, ldo, N, K, epilogue, norm, stream);
-}
-
 }  // extern "C"

@@ -92,100 +92,155 @@ w4_repack_kernel(uint8_t* __restrict__ qref, bf16_t* __restrict__ scales, bf16_t
 // ------------------------------------------------------------------------------------------ GEMV
 constexpr int kMaxRows = 16;  // rows per workgroup
 
-// RU = rows whose loads are in flight together per wave; MAXW = waves per workgroup the build allows (the register budget
-// follows from it: 8 waves -> 256 VGPRs, 16 waves -> 128)
+// diagnostic stamps (tools/microbench.py --stamps): 100 MHz clock of a few workgroups at phase boundaries
+__device__ unsigned long long* g_w4_dbg = nullptr;
+__device__ __forceinline__ void w4_stamp(int i) {
+    if (g_w4_dbg != nullptr && threadIdx.x == 0 && (blockIdx.x == 0 || blockIdx.x == gridDim.x / 2 || blockIdx.x == gridDim.x - 1)) {
+        const int b = blockIdx.x == 0 ? 0 : (blockIdx.x == gridDim.x - 1 ? 2 : 1);
+        g_w4_dbg[b * 8 + i] = __builtin_amdgcn_s_memrealtime();
+    }
+}
+
+// Workgroup shape: nslabs x wps waves.  Wave (slab c, j) streams slab c of row group j: RU consecutive rows whose loads
+// are all issued before the first use.  The activations (and the optional norm of them) are prepared ONCE per workgroup
+// and shared by its wps row groups: that is what makes a fused norm affordable (a 2-wave workgroup would re-normalise
+// 2 x 2048 activations for only 8 output rows).  MAXW = waves the build allows (8 -> 256 VGPRs, 16 -> 128).
 template <int M, bool DUAL, int RU, int MAXW>
 __global__ void __launch_bounds__(MAXW * 64)
 w4_gemv_kernel(const uint4* __restrict__ W, const uint4* __restrict__ W2, const bf16_t* __restrict__ x, int ldx,
-               const bf16_t* __restrict__ bias, const bf16_t* residual, int ldr, bf16_t* out, int ldo, int N,
-               int rows_per_wg, int epi, NormArgs na, W4Plan plan) {
+               const bf16_t* __restrict__ bias, const bf16_t* residual, int ldr, bf16_t* out, int ldo, int N, int K,
+               int wps, int epi, NormArgs na, W4Plan plan) {
     constexpr int NW = DUAL ? 2 : 1;
-    __shared__ float red[kMaxSlabs][kMaxRows * M * NW];
-    __shared__ float stat[kMaxSlabs];
+    extern __shared__ __attribute__((aligned(16))) unsigned char w4_smem[];  // normalised activations [M][K] bf16 (norm only)
+    __shared__ float red[MAXW][RU * M * NW];
+    __shared__ float stat[16];
 
+    w4_stamp(0);
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const W4Slab sl = plan.slab[wave];
+    const int nwaves = plan.nslabs * wps;
+    const int slab = wave / wps, j = wave % wps;
+    const W4Slab sl = plan.slab[slab];
     const bool active = lane < sl.nslices;
     const int lslice = active ? lane : sl.nslices - 1;
     const int gslice = sl.slice0 + lslice;
     const int gl = gslice / plan.Gs - sl.g0;
     const int64_t row16 = plan.row16;
-    const int r_begin = blockIdx.x * rows_per_wg;
-    const int r_end = min(N, r_begin + rows_per_wg);
+    const int wg_row0 = blockIdx.x * (wps * RU);
+    const int r0 = wg_row0 + j * RU;  // first row of this wave's group
 
-    constexpr int kU = RU;
-    uint4 w[NW][kU];
-    uint32_t mt[NW][kU];
-    // All kU row loads of a batch are issued back to back before anything waits.  Weights are read exactly once per
-    // token: non-temporal loads keep them from displacing the activations in L2.
-#define W4_LOAD_BATCH(R0)                                                                            \
-    _Pragma("unroll") for (int u = 0; u < kU; ++u) {                                                 \
-        const int64_t row = min((R0) + u, N - 1);                                                    \
-        const uint4* rec = W + row * row16;                                                          \
-        w[0][u] = load_nt16(rec + sl.w_off16 + lslice);                                              \
-        mt[0][u] = load_nt4(reinterpret_cast<const uint32_t*>(rec + sl.meta_off16) + gl);           \
-        if (DUAL) {                                                                                  \
-            const uint4* rec2 = W2 + row * row16;                                                    \
-            w[1][u] = load_nt16(rec2 + sl.w_off16 + lslice);                                         \
-            mt[1][u] = load_nt4(reinterpret_cast<const uint32_t*>(rec2 + sl.meta_off16) + gl);       \
-        }                                                                                            \
-    }
     // Load order matters because vmcnt retires in order: first the small L2-resident operands (activations, norm
-    // parameters), then the first batch of weights.  The norm prologue then only waits for the former while the
-    // HBM stream of the latter is already running.
-    // this lane's 32 activations per row of x, as 16 packed bf16 pairs
+    // parameters), then the weights.  The prologue then only waits for the former while the HBM stream is running.
     uint32_t xr[M][16];
-    float xs[M];
+    const int nthreads = nwaves * 64;
+    const int chunks = K >> 3;  // 16-byte units of a row of x
+    constexpr int kMaxChunkIt = 4;  // K <= 4 * 8 * nthreads is checked on the host for the norm path
+    uint4 cx[M][kMaxChunkIt], cw[kMaxChunkIt], cb[kMaxChunkIt];
+    if (na.kind == 0) {
 #pragma unroll
-    for (int m = 0; m < M; ++m) {
-        const uint4* xp = reinterpret_cast<const uint4*>(x + (int64_t)m * ldx + (int64_t)gslice * 32);
+        for (int m = 0; m < M; ++m) {
+            const uint4* xp = reinterpret_cast<const uint4*>(x + (int64_t)m * ldx + (int64_t)gslice * 32);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            uint4 v = xp[j];
-            if (!active) v = make_uint4(0, 0, 0, 0);
-            xr[m][4 * j + 0] = v.x;
-            xr[m][4 * j + 1] = v.y;
-            xr[m][4 * j + 2] = v.z;
-            xr[m][4 * j + 3] = v.w;
+            for (int q = 0; q < 4; ++q) {
+                uint4 v = xp[q];
+                if (!active) v = make_uint4(0, 0, 0, 0);
+                xr[m][4 * q + 0] = v.x;
+                xr[m][4 * q + 1] = v.y;
+                xr[m][4 * q + 2] = v.z;
+                xr[m][4 * q + 3] = v.w;
+            }
+        }
+    } else {
+        // cooperative: thread t owns chunks t, t + nthreads, ... of every row (and of the norm parameters)
+#pragma unroll
+        for (int it = 0; it < kMaxChunkIt; ++it) {
+            const int c = threadIdx.x + it * nthreads;
+            const int cc = c < chunks ? c : chunks - 1;
+            cw[it] = reinterpret_cast<const uint4*>(na.weight)[cc];
+            cb[it] = make_uint4(0, 0, 0, 0);
+            if (na.kind == 2 && na.bias != nullptr) cb[it] = reinterpret_cast<const uint4*>(na.bias)[cc];
+#pragma unroll
+            for (int m = 0; m < M; ++m) {
+                cx[m][it] = reinterpret_cast<const uint4*>(x + (int64_t)m * ldx)[cc];
+                if (c >= chunks) cx[m][it] = make_uint4(0, 0, 0, 0);
+            }
         }
     }
-    uint32_t nw[16], nb[16];
-    if (na.kind != 0) {
-        const uint4* wp = reinterpret_cast<const uint4*>(na.weight + (int64_t)gslice * 32);
-        const uint4* bp = reinterpret_cast<const uint4*>(na.bias + (int64_t)gslice * 32);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const uint4 v = wp[j];
-            nw[4 * j] = v.x; nw[4 * j + 1] = v.y; nw[4 * j + 2] = v.z; nw[4 * j + 3] = v.w;
-            uint4 b = make_uint4(0, 0, 0, 0);
-            if (na.kind == 2 && na.bias != nullptr) b = bp[j];
-            nb[4 * j] = b.x; nb[4 * j + 1] = b.y; nb[4 * j + 2] = b.z; nb[4 * j + 3] = b.w;
-        }
-    }
-    W4_LOAD_BATCH(r_begin)
 
-    if (na.kind != 0) {  // fused RMSNorm / LayerNorm of the input rows (wave-uniform branch)
+    uint4 w[NW][RU];
+    uint32_t mt[NW][RU];
+#pragma unroll
+    for (int u = 0; u < RU; ++u) {
+        const int64_t row = min(r0 + u, N - 1);
+        const uint4* rec = W + row * row16;
+        // weights are read exactly once per token: non-temporal loads keep them from displacing the activations in L2
+        w[0][u] = load_nt16(rec + sl.w_off16 + lslice);
+        mt[0][u] = load_nt4(reinterpret_cast<const uint32_t*>(rec + sl.meta_off16) + gl);
+        if (DUAL) {
+            const uint4* rec2 = W2 + row * row16;
+            w[1][u] = load_nt16(rec2 + sl.w_off16 + lslice);
+            mt[1][u] = load_nt4(reinterpret_cast<const uint32_t*>(rec2 + sl.meta_off16) + gl);
+        }
+    }
+
+    if (na.kind != 0) {  // fused RMSNorm / LayerNorm of the input rows, once per workgroup, through LDS
+        uint4* xn = reinterpret_cast<uint4*>(w4_smem);
 #pragma unroll
         for (int m = 0; m < M; ++m) {
             float s1 = 0.f;
 #pragma unroll
-            for (int i = 0; i < 16; ++i) s1 += norm_stat1(xr[m][i], na.kind);
-            s1 = block_sum_waves(s1, stat, plan.nslabs);
+            for (int it = 0; it < kMaxChunkIt; ++it) {
+                const uint32_t dw[4] = {cx[m][it].x, cx[m][it].y, cx[m][it].z, cx[m][it].w};
+#pragma unroll
+                for (int i = 0; i < 4; ++i) s1 += norm_stat1(dw[i], na.kind);  // chunks past the row hold zeros
+            }
+            s1 = block_sum_waves(s1, stat, nwaves);
             float mean = 0.f, r;
             if (na.kind == 2) {
                 mean = s1 / (float)na.d;
                 float s2 = 0.f;
 #pragma unroll
-                for (int i = 0; i < 16; ++i) s2 += active ? norm_stat2(xr[m][i], mean) : 0.f;
-                r = norm_scale(na, block_sum_waves(s2, stat, plan.nslabs));
+                for (int it = 0; it < kMaxChunkIt; ++it) {
+                    if (threadIdx.x + it * nthreads < chunks) {
+                        const uint32_t dw[4] = {cx[m][it].x, cx[m][it].y, cx[m][it].z, cx[m][it].w};
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) s2 += norm_stat2(dw[i], mean);
+                    }
+                }
+                r = norm_scale(na, block_sum_waves(s2, stat, nwaves));
             } else {
                 r = norm_scale(na, s1);
             }
 #pragma unroll
-            for (int i = 0; i < 16; ++i) xr[m][i] = active ? norm_apply(xr[m][i], nw[i], nb[i], na.kind, mean, r) : 0u;
+            for (int it = 0; it < kMaxChunkIt; ++it) {
+                const int c = threadIdx.x + it * nthreads;
+                if (c < chunks) {
+                    const uint32_t dx[4] = {cx[m][it].x, cx[m][it].y, cx[m][it].z, cx[m][it].w};
+                    const uint32_t dwt[4] = {cw[it].x, cw[it].y, cw[it].z, cw[it].w};
+                    const uint32_t dbs[4] = {cb[it].x, cb[it].y, cb[it].z, cb[it].w};
+                    uint32_t o[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) o[i] = norm_apply(dx[i], dwt[i], dbs[i], na.kind, mean, r);
+                    xn[(int64_t)m * chunks + c] = make_uint4(o[0], o[1], o[2], o[3]);
+                }
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int m = 0; m < M; ++m) {
+            const uint4* xl = xn + (int64_t)m * chunks + (int64_t)gslice * 4;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                uint4 v = xl[q];
+                if (!active) v = make_uint4(0, 0, 0, 0);
+                xr[m][4 * q + 0] = v.x;
+                xr[m][4 * q + 1] = v.y;
+                xr[m][4 * q + 2] = v.z;
+                xr[m][4 * q + 3] = v.w;
+            }
         }
     }
+    float xs[M];
 #pragma unroll
     for (int m = 0; m < M; ++m) {
         float s = 0.f;
@@ -193,72 +248,287 @@ w4_gemv_kernel(const uint4* __restrict__ W, const uint4* __restrict__ W2, const 
         for (int i = 0; i < 16; ++i) s += bflo(xr[m][i]) + bfhi(xr[m][i]);
         xs[m] = s;
     }
+    w4_stamp(1);
 
-    for (int r0 = r_begin; r0 < r_end; r0 += kU) {
-        if (r0 != r_begin) {
-            W4_LOAD_BATCH(r0)
-        }
 #pragma unroll
-        for (int u = 0; u < kU; ++u) {
+    for (int u = 0; u < RU; ++u) {
 #pragma unroll
-            for (int q = 0; q < NW; ++q) {
-                const float s = bflo(mt[q][u]);
-                const float zz = 128.0f + bfhi(mt[q][u]);
+        for (int q = 0; q < NW; ++q) {
+            const float s = bflo(mt[q][u]);
+            const float zz = 128.0f + bfhi(mt[q][u]);
 #pragma unroll
-                for (int m = 0; m < M; ++m) {
-                    const float p = w4_slice_dot(w[q][u], xr[m]);
-                    float v = s * (p - zz * xs[m]);
-                    v = wave_sum_to_lane63(v);
-                    if (lane == 63) red[wave][((r0 - r_begin + u) * M + m) * NW + q] = v;
-                }
+            for (int m = 0; m < M; ++m) {
+                const float p = w4_slice_dot(w[q][u], xr[m]);
+                const float v = wave_sum_to_lane63(s * (p - zz * xs[m]));
+                if (lane == 63) red[wave][(u * M + m) * NW + q] = v;
             }
         }
     }
-#undef W4_LOAD_BATCH
+    w4_stamp(2);
     __syncthreads();
-    const int nrows = r_end - r_begin;
-    if ((int)threadIdx.x < nrows * M) {
-        const int ur = threadIdx.x / M, m = threadIdx.x % M;
-        float a0 = 0.f, a1 = 0.f;
-        for (int c = 0; c < plan.nslabs; ++c) {
-            a0 += red[c][(ur * M + m) * NW];
-            if (DUAL) a1 += red[c][(ur * M + m) * NW + 1];
+    w4_stamp(3);
+    // epilogue: one thread per (row of the workgroup, m); sums the slabs in a fixed order
+    if ((int)threadIdx.x < wps * RU * M) {
+        const int m = threadIdx.x % M, ur = threadIdx.x / M;
+        const int jj = ur / RU, u = ur % RU;
+        const int col = wg_row0 + ur;
+        if (col < N) {
+            float a0 = 0.f, a1 = 0.f;
+            for (int c = 0; c < plan.nslabs; ++c) {
+                a0 += red[c * wps + jj][(u * M + m) * NW];
+                if (DUAL) a1 += red[c * wps + jj][(u * M + m) * NW + 1];
+            }
+            out[(int64_t)m * ldo + col] =
+                apply_epilogue(epi, a0, a1, bias, residual ? residual + (int64_t)m * ldr : nullptr, col);
         }
-        const int col = r_begin + ur;
-        out[(int64_t)m * ldo + col] =
-            apply_epilogue(epi, a0, a1, bias, residual ? residual + (int64_t)m * ldr : nullptr, col);
     }
+    w4_stamp(4);
 }
 
-static int g_rows_per_wg_override = 0;  // tuning hook (tools/microbench.py), 0 = heuristic
+// ------------------------------------------------------------------------------------------ streaming GEMV (M = 1)
+// The burst kernel above issues every load of the launch at once: the whole matrix is in flight, the data comes back in
+// request order per CU, and only then do the dot products run - 2-3 us of VALU work that nothing overlaps (measured with
+// in-kernel stamps).  This kernel is the decode-path replacement: about one workgroup per CU, each wave walks SEVERAL
+// row groups with a two-deep register pipeline (the loads of group i+2 are requested before group i is consumed), so the
+// HBM stream runs under the arithmetic, and the activation / norm prologue is paid once per workgroup under the first loads.
+//   workgroup b owns row groups b, b + G, b + 2G, ...; its t-th group goes to wave column j = t % wps in batch t / wps;
+//   the nslabs waves of a column split K; per batch one barrier: slab partials -> LDS (double-buffered) -> epilogue.
+template <bool DUAL, int RU, int MAXW>
+__global__ void __launch_bounds__(MAXW * 64)
+w4_stream_kernel(const uint4* __restrict__ W, const uint4* __restrict__ W2, const bf16_t* __restrict__ x,
+                 const bf16_t* __restrict__ bias, const bf16_t* residual, bf16_t* out, int N, int K, int wps, int epi,
+                 NormArgs na, W4Plan plan) {
+    constexpr int NW = DUAL ? 2 : 1;
+    extern __shared__ __attribute__((aligned(16))) unsigned char w4_smem[];  // normalised activations [K] bf16 (norm only)
+    __shared__ float red[2][MAXW][RU * NW];
+    __shared__ float stat[16];
 
-static int pick_rows_per_wg(int N) {
-    if (g_rows_per_wg_override > 0) return g_rows_per_wg_override;
-    if (N >= 16 * 2048) return 16;
-    return 8;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int nwaves = plan.nslabs * wps;
+    const int slab = wave / wps, j = wave % wps;
+    const W4Slab sl = plan.slab[slab];
+    const bool active = lane < sl.nslices;
+    const int lslice = active ? lane : sl.nslices - 1;
+    const int gslice = sl.slice0 + lslice;
+    const int gl = gslice / plan.Gs - sl.g0;
+    const int64_t row16 = plan.row16;
+    const int G = gridDim.x;
+    const int ngroups = (N + RU - 1) / RU;
+    const int T = ((int)blockIdx.x < ngroups) ? (ngroups - (int)blockIdx.x + G - 1) / G : 0;  // groups of this workgroup
+    const int batches = (T + wps - 1) / wps;
+
+    // ---- small L2-resident operands first (vmcnt retires in order), then the first two batches of weights
+    uint32_t xr[16];
+    const int nthreads = nwaves * 64;
+    const int chunks = K >> 3;
+    constexpr int kMaxChunkIt = 4;
+    uint4 cx[kMaxChunkIt], cw[kMaxChunkIt], cb[kMaxChunkIt];
+    if (na.kind == 0) {
+        const uint4* xp = reinterpret_cast<const uint4*>(x + (int64_t)gslice * 32);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            uint4 v = xp[q];
+            if (!active) v = make_uint4(0, 0, 0, 0);
+            xr[4 * q + 0] = v.x; xr[4 * q + 1] = v.y; xr[4 * q + 2] = v.z; xr[4 * q + 3] = v.w;
+        }
+    } else {
+#pragma unroll
+        for (int it = 0; it < kMaxChunkIt; ++it) {
+            const int c = threadIdx.x + it * nthreads;
+            const int cc = c < chunks ? c : chunks - 1;
+            cw[it] = reinterpret_cast<const uint4*>(na.weight)[cc];
+            cb[it] = make_uint4(0, 0, 0, 0);
+            if (na.kind == 2 && na.bias != nullptr) cb[it] = reinterpret_cast<const uint4*>(na.bias)[cc];
+            cx[it] = reinterpret_cast<const uint4*>(x)[cc];
+            if (c >= chunks) cx[it] = make_uint4(0, 0, 0, 0);
+        }
+    }
+
+    uint4 w[2][NW][RU];
+    uint32_t mt[2][NW][RU];
+    // rows of batch `bi` of this wave: group t = bi * wps + j of the workgroup, i.e. global group blockIdx + t * G
+#define W4S_LOAD(BUF, BI)                                                                              \
+    {                                                                                                  \
+        const int t_ = (BI) * wps + j;                                                                 \
+        const int r0_ = ((int)blockIdx.x + min(t_, T - 1) * G) * RU;                                   \
+        _Pragma("unroll") for (int u = 0; u < RU; ++u) {                                               \
+            const int64_t row = min(r0_ + u, N - 1);                                                   \
+            const uint4* rec = W + row * row16;                                                        \
+            w[BUF][0][u] = load_nt16(rec + sl.w_off16 + lslice);                                       \
+            mt[BUF][0][u] = load_nt4(reinterpret_cast<const uint32_t*>(rec + sl.meta_off16) + gl);     \
+            if (DUAL) {                                                                                \
+                const uint4* rec2 = W2 + row * row16;                                                  \
+                w[BUF][1][u] = load_nt16(rec2 + sl.w_off16 + lslice);                                  \
+                mt[BUF][1][u] = load_nt4(reinterpret_cast<const uint32_t*>(rec2 + sl.meta_off16) + gl); \
+            }                                                                                          \
+        }                                                                                              \
+    }
+    if (batches > 0) W4S_LOAD(0, 0)
+    if (batches > 1) W4S_LOAD(1, 1)
+
+    if (na.kind != 0) {  // fused RMSNorm / LayerNorm, once per workgroup, through LDS
+        uint4* xn = reinterpret_cast<uint4*>(w4_smem);
+        float s1 = 0.f;
+#pragma unroll
+        for (int it = 0; it < kMaxChunkIt; ++it) {
+            const uint32_t dw[4] = {cx[it].x, cx[it].y, cx[it].z, cx[it].w};
+#pragma unroll
+            for (int i = 0; i < 4; ++i) s1 += norm_stat1(dw[i], na.kind);
+        }
+        s1 = block_sum_waves(s1, stat, nwaves);
+        float mean = 0.f, r;
+        if (na.kind == 2) {
+            mean = s1 / (float)na.d;
+            float s2 = 0.f;
+#pragma unroll
+            for (int it = 0; it < kMaxChunkIt; ++it) {
+                if (threadIdx.x + it * nthreads < chunks) {
+                    const uint32_t dw[4] = {cx[it].x, cx[it].y, cx[it].z, cx[it].w};
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) s2 += norm_stat2(dw[i], mean);
+                }
+            }
+            r = norm_scale(na, block_sum_waves(s2, stat, nwaves));
+        } else {
+            r = norm_scale(na, s1);
+        }
+#pragma unroll
+        for (int it = 0; it < kMaxChunkIt; ++it) {
+            const int c = threadIdx.x + it * nthreads;
+            if (c < chunks) {
+                const uint32_t dx[4] = {cx[it].x, cx[it].y, cx[it].z, cx[it].w};
+                const uint32_t dwt[4] = {cw[it].x, cw[it].y, cw[it].z, cw[it].w};
+                const uint32_t dbs[4] = {cb[it].x, cb[it].y, cb[it].z, cb[it].w};
+                uint32_t o[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) o[i] = norm_apply(dx[i], dwt[i], dbs[i], na.kind, mean, r);
+                xn[c] = make_uint4(o[0], o[1], o[2], o[3]);
+            }
+        }
+        __syncthreads();
+        const uint4* xl = xn + (int64_t)gslice * 4;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            uint4 v = xl[q];
+            if (!active) v = make_uint4(0, 0, 0, 0);
+            xr[4 * q + 0] = v.x; xr[4 * q + 1] = v.y; xr[4 * q + 2] = v.z; xr[4 * q + 3] = v.w;
+        }
+    }
+    float xs = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) xs += bflo(xr[i]) + bfhi(xr[i]);
+
+    // one pipeline step: consume buffer BUF (batch BI), refill it with batch BI + 2, barrier, epilogue of batch BI
+#define W4S_STEP(BUF, BI)                                                                                          \
+    {                                                                                                              \
+        _Pragma("unroll") for (int u = 0; u < RU; ++u) {                                                           \
+            _Pragma("unroll") for (int q = 0; q < NW; ++q) {                                                       \
+                const float s_ = bflo(mt[BUF][q][u]);                                                              \
+                const float zz_ = 128.0f + bfhi(mt[BUF][q][u]);                                                    \
+                const float p_ = w4_slice_dot(w[BUF][q][u], xr);                                                   \
+                const float v_ = wave_sum_to_lane63(s_ * (p_ - zz_ * xs));                                         \
+                if (lane == 63) red[(BI) & 1][wave][u * NW + q] = v_;                                              \
+            }                                                                                                      \
+        }                                                                                                          \
+        if ((BI) + 2 < batches) W4S_LOAD(BUF, (BI) + 2)                                                            \
+        __syncthreads();                                                                                           \
+        if ((int)threadIdx.x < wps * RU) {                                                                         \
+            const int jj = threadIdx.x / RU, u = threadIdx.x % RU;                                                 \
+            const int t_ = (BI) * wps + jj;                                                                        \
+            const int col = ((int)blockIdx.x + t_ * G) * RU + u;                                                   \
+            if (t_ < T && col < N) {                                                                               \
+                float a0 = 0.f, a1 = 0.f;                                                                          \
+                for (int c = 0; c < plan.nslabs; ++c) {                                                            \
+                    a0 += red[(BI) & 1][c * wps + jj][u * NW];                                                     \
+                    if (DUAL) a1 += red[(BI) & 1][c * wps + jj][u * NW + 1];                                       \
+                }                                                                                                  \
+                out[col] = apply_epilogue(epi, a0, a1, bias, residual, col);                                       \
+            }                                                                                                      \
+        }                                                                                                          \
+    }
+    for (int bi = 0; bi < batches; bi += 2) {
+        W4S_STEP(0, bi)
+        if (bi + 1 < batches) W4S_STEP(1, bi + 1)
+    }
+#undef W4S_STEP
+#undef W4S_LOAD
+}
+
+static int g_stream_wgs_per_cu_x2 = 0;  // tuning hook: workgroups per 128 CUs ... (0 = heuristic)
+
+static int g_wps_override = 0;  // tuning hook (tools/microbench.py): row groups per workgroup, 0 = heuristic
+
+// row groups per workgroup: aim at ~640 workgroups per launch, bounded by the waves the build allows
+static int pick_wps(int N, int RU, int nslabs, int maxw, bool norm) {
+    int cap = maxw / nslabs;
+    if (cap < 1) cap = 1;
+    int wps = g_wps_override > 0 ? g_wps_override : (int)((N + (int64_t)RU * 320) / ((int64_t)RU * 640));
+    if (norm && wps < 2 && cap >= 2 && g_wps_override == 0) wps = 2;  // share the norm over at least two row groups
+    if (wps < 1) wps = 1;
+    if (wps > cap) wps = cap;
+    return wps;
 }
 
 template <int M, bool DUAL, int RU, int MAXW>
 static int w4_gemv_launch_v(const void* packed, const void* packed2, const void* x, int ldx, const void* bias,
-                            const void* residual, int ldr, void* out, int ldo, int N, int epi, const NormArgs& na,
+                            const void* residual, int ldr, void* out, int ldo, int N, int K, int epi, const NormArgs& na,
                             const W4Plan& plan, hipStream_t st) {
-    int R = pick_rows_per_wg(N);
-    if (R < RU) R = RU;
-    const dim3 grid((N + R - 1) / R), block(64 * plan.nslabs);
-    return launch(DUAL ? K_W4_GEMV_DUAL : K_W4_GEMV, w4_gemv_kernel<M, DUAL, RU, MAXW>, grid, block, 0, st,
+    const int wps = pick_wps(N, RU, plan.nslabs, MAXW, na.kind != 0);
+    const int R = wps * RU;
+    const int nthreads = 64 * plan.nslabs * wps;
+    size_t lds = 0;
+    if (na.kind != 0) {
+        PARROT_UNSUPPORTED((K >> 3) <= 4 * nthreads, "w4_gemv: fused norm needs K <= %d with this workgroup shape", 32 * nthreads);
+        lds = (size_t)M * K * 2;
+        PARROT_UNSUPPORTED(lds <= 64 * 1024, "w4_gemv: fused norm needs %zu B of LDS", lds);
+    }
+    const dim3 grid((N + R - 1) / R), block(nthreads);
+    return launch(DUAL ? K_W4_GEMV_DUAL : K_W4_GEMV, w4_gemv_kernel<M, DUAL, RU, MAXW>, grid, block, lds, st,
                   (const uint4*)packed, (const uint4*)packed2, (const bf16_t*)x, ldx, (const bf16_t*)bias,
-                  (const bf16_t*)residual, ldr, (bf16_t*)out, ldo, N, R, epi, na, plan);
+                  (const bf16_t*)residual, ldr, (bf16_t*)out, ldo, N, K, wps, epi, na, plan);
+}
+
+static int g_use_stream = 1;  // tuning hook: 0 = burst kernel for M = 1 as well
+
+template <bool DUAL, int RU, int MAXW>
+static int w4_stream_launch(const void* packed, const void* packed2, const void* x, const void* bias, const void* residual,
+                            void* out, int N, int K, int epi, const NormArgs& na, const W4Plan& plan, hipStream_t st) {
+    int wps = MAXW / plan.nslabs;
+    if (wps > 2) wps = 2;  // 2 wave columns per workgroup (4 waves at K = 4096, 6 at K = 11008 with wps 1)
+    if (g_wps_override > 0 && g_wps_override * plan.nslabs <= MAXW) wps = g_wps_override;
+    if (wps < 1) wps = 1;
+    const int ngroups = (N + RU - 1) / RU;
+    int G = g_stream_wgs_per_cu_x2 > 0 ? 128 * g_stream_wgs_per_cu_x2 : 256;  // ~ one workgroup per CU
+    if (G * wps > ngroups) G = (ngroups + wps - 1) / wps;
+    const int nthreads = 64 * plan.nslabs * wps;
+    size_t lds = 0;
+    if (na.kind != 0) {
+        PARROT_UNSUPPORTED((K >> 3) <= 4 * nthreads, "w4_gemv: fused norm needs K <= %d with this workgroup shape", 32 * nthreads);
+        lds = (size_t)K * 2;
+    }
+    return launch(DUAL ? K_W4_GEMV_DUAL : K_W4_GEMV, w4_stream_kernel<DUAL, RU, MAXW>, dim3(G), dim3(nthreads), lds, st,
+                  (const uint4*)packed, (const uint4*)packed2, (const bf16_t*)x, (const bf16_t*)bias, (const bf16_t*)residual,
+                  (bf16_t*)out, N, K, wps, epi, na, plan);
 }
 
 template <int M>
 static int w4_gemv_launch(const void* packed, const void* packed2, const void* x, int ldx, const void* bias,
-                          const void* residual, int ldr, void* out, int ldo, int N, int epi, const NormArgs& na,
+                          const void* residual, int ldr, void* out, int ldo, int N, int K, int epi, const NormArgs& na,
                           const W4Plan& plan, hipStream_t st) {
-    // rows in flight: 8 for the single-row decode kernel, 4 when a second weight or more rows share the registers
+    if (M == 1 && g_use_stream) {
+        const bool dual = epi == PARROT_EPI_SWIGLU;
+        if (plan.nslabs <= 8)
+            return dual ? w4_stream_launch<true, 4, 8>(packed, packed2, x, bias, residual, out, N, K, epi, na, plan, st)
+                        : w4_stream_launch<false, 8, 8>(packed, packed2, x, bias, residual, out, N, K, epi, na, plan, st);
+        return dual ? w4_stream_launch<true, 2, 16>(packed, packed2, x, bias, residual, out, N, K, epi, na, plan, st)
+                    : w4_stream_launch<false, 4, 16>(packed, packed2, x, bias, residual, out, N, K, epi, na, plan, st);
+    }
+    // rows in flight per wave: 8 for the single-row decode kernel, fewer when a second weight or more rows share the registers
     constexpr int RU1 = (M == 1) ? 8 : 4;
     constexpr int RU2 = (M <= 2) ? 4 : 2;
 #define PARROT_W4_GO(DUALV, RUV, MAXWV) \
-    return w4_gemv_launch_v<M, DUALV, RUV, MAXWV>(packed, packed2, x, ldx, bias, residual, ldr, out, ldo, N, epi, na, plan, st)
+    return w4_gemv_launch_v<M, DUALV, RUV, MAXWV>(packed, packed2, x, ldx, bias, residual, ldr, out, ldo, N, K, epi, na, plan, st)
     if (plan.nslabs <= 8) {
         if (epi == PARROT_EPI_SWIGLU) PARROT_W4_GO(true, RU2, 8);
         PARROT_W4_GO(false, RU1, 8);
@@ -275,8 +545,20 @@ using namespace parrot;
 extern "C" {
 
 // tuning hook, not part of the public header: rows of output per workgroup (0 = heuristic)
-int parrot_tune_w4_rows_per_wg(int rows) {
-    g_rows_per_wg_override = (rows == 4 || rows == 8 || rows == 16) ? rows : 0;
+int parrot_tune_w4_stamps(void* dbg24_u64) {  // diagnostic: device buffer of 24 uint64, or NULL to switch off
+    unsigned long long* p = (unsigned long long*)dbg24_u64;
+    hipError_t e = hipMemcpyToSymbol(HIP_SYMBOL(g_w4_dbg), &p, sizeof(p));
+    return e == hipSuccess ? PARROT_OK : hip_fail(e, "hipMemcpyToSymbol");
+}
+
+int parrot_tune_w4_stream(int use_stream, int wgs_per_128_cus) {  // diagnostic / tuning
+    g_use_stream = use_stream;
+    g_stream_wgs_per_cu_x2 = wgs_per_128_cus;
+    return PARROT_OK;
+}
+
+int parrot_tune_w4_rows_per_wg(int wps) {  // (name kept) row groups per workgroup, 0 = heuristic
+    g_wps_override = (wps >= 1 && wps <= 8) ? wps : 0;
     return PARROT_OK;
 }
 
@@ -324,22 +606,14 @@ int parrot_w4_gemv(const void* packed, const void* packed2, const void* x, int l
         const void* rm = rb ? rb + (int64_t)m0 * ldr : nullptr;
         void* om = ob + (int64_t)m0 * ldo;
         switch (mm) {
-            case 1: rc = w4_gemv_launch<1>(packed, packed2, xm, ldx, bias, rm, ldr, om, ldo, N, epilogue, na, plan, st); break;
-            case 2: rc = w4_gemv_launch<2>(packed, packed2, xm, ldx, bias, rm, ldr, om, ldo, N, epilogue, na, plan, st); break;
-            case 3: rc = w4_gemv_launch<3>(packed, packed2, xm, ldx, bias, rm, ldr, om, ldo, N, epilogue, na, plan, st); break;
-            default: rc = w4_gemv_launch<4>(packed, packed2, xm, ldx, bias, rm, ldr, om, ldo, N, epilogue, na, plan, st); break;
+            case 1: rc = w4_gemv_launch<1>(packed, packed2, xm, ldx, bias, rm, ldr, om, ldo, N, K, epilogue, na, plan, st); break;
+            case 2: rc = w4_gemv_launch<2>(packed, packed2, xm, ldx, bias, rm, ldr, om, ldo, N, K, epilogue, na, plan, st); break;
+            case 3: rc = w4_gemv_launch<3>(packed, packed2, xm, ldx, bias, rm, ldr, om, ldo, N, K, epilogue, na, plan, st); break;
+            default: rc = w4_gemv_launch<4>(packed, packed2, xm, ldx, bias, rm, ldr, om, ldo, N, K, epilogue, na, plan, st); break;
         }
         if (rc != PARROT_OK) return rc;
     }
     return PARROT_OK;
-}
-
-// Prefill entry point.  Round 1: row blocks of 4 through the GEMV kernel (weights re-read per block);
-// the MFMA dequant-to-LDS kernel replaces this body without changing the contract.
-int parrot_w4_gemm(const void* packed, const void* packed2, const void* x, int ldx, int M, const void* bias,
-                   const void* residual, int ldr, void* out, int ldo, int N, int K, int group, int epilogue,
-                   const parrot_norm_t* norm, void* stream) {
-    return parrot_w4_gemv(packed, packed2, x, ldx, M, bias, residual, ldr, out, ldo, N, K, group, epilogue, norm, stream);
 }
 
 }  // extern "C"

@@ -68,6 +68,18 @@ class Norm:
         return _hip.ParrotNorm(self.kind, ptr(w), ptr(b), self.eps, RMSNORM_RSQRT_MODE)
 
 
+def _prenorm(x: torch.Tensor, norm: Optional["Norm"]):
+    """Prefill (more rows than the GEMV kernels take): apply the norm with the stand-alone kernel first."""
+    if norm is None or (x.shape[0] <= GEMV_MAX_ROWS and x.shape[0] * x.shape[1] * 2 <= 60000):
+        return x, norm  # the fused prologue keeps the normalised rows in LDS (<= 64 KB)
+    xn = torch.empty_like(x)
+    if norm.kind == 1:
+        rmsnorm(x, norm.weight, norm.eps, xn)
+    else:
+        layernorm(x, norm.weight, norm.bias, norm.eps, xn)
+    return xn, None
+
+
 def _norm_arg(norm: Optional[Norm], K: int):
     return None if norm is None else C.byref(norm.c_struct(K))
 
@@ -76,6 +88,7 @@ def _norm_arg(norm: Optional[Norm], K: int):
 def bf16_linear(weight: torch.Tensor, x: torch.Tensor, out: torch.Tensor, *, bias=None, epilogue=EPI_NONE,
                 residual=None, weight2=None, norm: Optional[Norm] = None) -> torch.Tensor:
     _rows(x, "bf16_linear"), _rows(out, "bf16_linear")
+    x, norm = _prenorm(x, norm)
     N, K = weight.shape
     if weight.dtype != torch.bfloat16 or not weight.is_contiguous():
         raise ParrotHipError("bf16_linear: weight must be contiguous bf16 (out_features, in_features)")
@@ -112,14 +125,19 @@ def w4_repack(quant_weight: torch.Tensor, scales: torch.Tensor, zeros: torch.Ten
 def w4_linear(packed: torch.Tensor, N: int, K: int, group: int, x: torch.Tensor, out: torch.Tensor, *, bias=None,
               epilogue=EPI_NONE, residual=None, packed2=None, norm: Optional[Norm] = None) -> torch.Tensor:
     _rows(x, "w4_linear"), _rows(out, "w4_linear")
+    x, norm = _prenorm(x, norm)
     M = x.shape[0]
     if x.shape[1] != K or out.shape[1] != N:
         raise ParrotHipError(f"w4_linear: x {tuple(x.shape)} / out {tuple(out.shape)} do not match N={N} K={K}")
     lib = _hip.load()
-    fn = lib.parrot_w4_gemv if M <= GEMV_MAX_ROWS else lib.parrot_w4_gemm
-    check(fn(ptr(packed), ptr(packed2), ptr(x), x.stride(0), M, ptr(_opt_vec(bias, N, "bias")), ptr(residual),
-             residual.stride(0) if residual is not None else 0, ptr(out), out.stride(0), N, K, group, epilogue,
-             _norm_arg(norm, K), stream()), "parrot_w4_gemv/gemm")
+    args = (ptr(packed), ptr(packed2), ptr(x), x.stride(0), M, ptr(_opt_vec(bias, N, "bias")), ptr(residual),
+            residual.stride(0) if residual is not None else 0, ptr(out), out.stride(0), N, K, group, epilogue,
+            _norm_arg(norm, K))
+    if M <= GEMV_MAX_ROWS:
+        check(lib.parrot_w4_gemv(*args, stream()), "parrot_w4_gemv")
+    else:  # prefill: MFMA kernel; needs the per-group activation sums workspace
+        ws = torch.empty((max(1, lib.parrot_gemm_workspace_floats(M, K, group)),), dtype=torch.float32, device=x.device)
+        check(lib.parrot_w4_gemm(*args, ptr(ws), stream()), "parrot_w4_gemm")
     return out
 
 

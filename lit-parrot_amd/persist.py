@@ -15,42 +15,7 @@ from ._hip import EPI_GELU, EPI_NONE, EPI_RESIDUAL, EPI_SWIGLU, ParrotHipError, 
 from .quantize.gptq import ColBlockQuantizedLinear
 from .rmsnorm import RMSNorm
 
-PK_GEMV, PK_ATTN, PK_ARGMAX = 0, 1, 2
-PK_MAX_SLABS = 12
-PK_WGS = 256
-
-
-class PkSlab(C.Structure):
-    _fields_ = [(n, C.c_int32) for n in ("slice0", "nslices", "g0", "w_off16", "meta_off16")]
-
-
-class PkOp(C.Structure):  # parrot_pk_op_t
-    _fields_ = (
-        [(n, C.c_int32) for n in ("type", "epilogue", "N", "K", "nslabs", "row16", "Gs", "norm_kind")]
-        + [("norm_eps", C.c_float)]
-        + [(n, C.c_int32) for n in ("x_from_embedding", "res_from_embedding", "track_argmax")]
-        + [(n, C.c_void_p) for n in ("W", "W2", "x", "norm_w", "norm_b", "bias", "residual", "out", "k_cache", "v_cache")]
-        + [("slab", PkSlab * PK_MAX_SLABS)]
-    )
-
-
-class PkState(C.Structure):  # parrot_pk_state_t
-    _fields_ = (
-        [("ops", C.c_void_p), ("nops", C.c_int32), ("d", C.c_int32)]
-        + [(n, C.c_void_p) for n in ("tokens", "pos", "wte", "rope_cos", "rope_sin")]
-        + [(n, C.c_int32) for n in ("n_elem", "n_groups", "q_per_kv", "hs", "S", "V", "rsqrt_mode", "lds_x_bytes")]
-        + [(n, C.c_void_p) for n in ("attn_ws", "tickets", "counters", "err", "argmax_val", "argmax_idx", "dbg")]
-    )
-
-
-def _declare(lib) -> None:
-    if getattr(lib, "_pk_declared", False):
-        return
-    lib.parrot_pk_fill_w4.restype = C.c_int
-    lib.parrot_pk_fill_w4.argtypes = [C.POINTER(PkOp), C.c_int, C.c_int, C.c_int]
-    lib.parrot_pk_step.restype = C.c_int
-    lib.parrot_pk_step.argtypes = [C.POINTER(PkState), C.c_void_p]
-    lib._pk_declared = True
+from ._hip import PK_ARGMAX, PK_ATTN, PK_GEMV, PK_MAX_SLABS, PK_WGS, PkOp, PkSlab, PkState
 
 
 def _norm_fields(mod) -> tuple:
@@ -76,7 +41,6 @@ class PersistentStep:
         if PK_WGS % c.n_query_groups or c.q_per_kv > 16:
             return "query group count"
         lib = _hip.load()
-        _declare(lib)
         probe = PkOp()
         for m in linears:
             if lib.parrot_pk_fill_w4(C.byref(probe), m.out_features, m.in_features, m.tile_cols) != 0:

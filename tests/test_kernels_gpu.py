@@ -146,6 +146,67 @@ def test_w4_module_forward_shape_and_bad_inputs():
         lin(x.to(DEV).float())  # fp32 activations: not built
 
 
+# ------------------------------------------------------------------------------------------------ MFMA prefill GEMMs
+@pytest.mark.parametrize("N,K,group", [(96, 512, 128), (256, 4096, 128), (200, 352, 128), (128, 256, -1), (64, 256, 32), (130, 11008, 128)])
+@pytest.mark.parametrize("M", [9, 37, 128, 200])
+def test_w4_gemm_matches_oracle_and_the_gemv(N, K, group, M):
+    qw, s, z, tc, Wd = make_w4(N, K, group, 30)
+    g = gen(31)
+    x = torch.randn(M, K, generator=g).to(BF)
+    bias = (torch.randn(N, generator=g) * 0.1).to(BF)
+    lin = w4_module(qw, s, z, N, K, group, bias)
+    out = torch.empty((M, N), dtype=BF, device=DEV)
+    lin.hip_linear(x.to(DEV), out)  # M > 8 -> parrot_w4_gemm (matrix cores)
+    want = expected_epilogue(x.double() @ Wd.t(), None, bias, None, EPI_NONE)
+    assert_bf16_close(out, want, ulps=1, atol=3e-3, what=f"w4_gemm N={N} K={K} g={group} M={M}")
+    # same numerics as the decode GEMV (row blocks of <= 8): identical up to fp32 summation order
+    ref = torch.empty_like(out)
+    for m0 in range(0, M, 8):
+        lin.hip_linear(x[m0:m0 + 8].to(DEV), ref[m0:m0 + 8])
+    assert_bf16_close(out, ref.float(), ulps=1, atol=3e-3, what="w4_gemm vs gemv")
+
+
+@pytest.mark.parametrize("epi", [EPI_RESIDUAL, EPI_GELU, EPI_SWIGLU])
+@pytest.mark.parametrize("kind", ["w4", "bf16"])
+def test_gemm_epilogues(epi, kind):
+    N, K, M = 160, 512, 70
+    g = gen(32)
+    x, res = torch.randn(M, K, generator=g).to(BF), torch.randn(M, N, generator=g).to(BF)
+    bias = None if epi == EPI_SWIGLU else (torch.randn(N, generator=g) * 0.1).to(BF)
+    out = torch.empty((M, N), dtype=BF, device=DEV)
+    if kind == "w4":
+        qw, s, z, tc, Wd = make_w4(N, K, 128, 33)
+        qw2, s2, z2, _, Wd2 = make_w4(N, K, 128, 34)
+        lin, lin2 = w4_module(qw, s, z, N, K, 128, bias), w4_module(qw2, s2, z2, N, K, 128)
+        lin.hip_linear(x.to(DEV), out, epilogue=epi, residual=res.to(DEV) if epi == EPI_RESIDUAL else None,
+                       partner=lin2 if epi == EPI_SWIGLU else None)
+    else:
+        W, W2 = ((torch.randn(N, K, generator=g) * 0.05).to(BF) for _ in range(2))
+        Wd, Wd2 = W.double(), W2.double()
+        ops.bf16_linear(W.to(DEV), x.to(DEV), out, bias=bias.to(DEV) if bias is not None else None, epilogue=epi,
+                        residual=res.to(DEV) if epi == EPI_RESIDUAL else None, weight2=W2.to(DEV) if epi == EPI_SWIGLU else None)
+    want = expected_epilogue(x.double() @ Wd.t(), x.double() @ Wd2.t(), bias, res, epi)
+    assert_bf16_close(out, want, ulps=1, atol=3e-3, what=f"{kind} gemm epilogue {epi}")
+
+
+@pytest.mark.parametrize("N,K", [(64, 128), (300, 768), (128, 4096), (1000, 352)])
+@pytest.mark.parametrize("M", [9, 64, 130])
+def test_bf16_gemm_matches_oracle(N, K, M):
+    g = gen(35)
+    W = (torch.randn(N, K, generator=g) * 0.02).to(BF)
+    x = torch.randn(M, K, generator=g).to(BF)
+    bias = (torch.randn(N, generator=g) * 0.1).to(BF)
+    out = torch.empty((M, N), dtype=BF, device=DEV)
+    ops.bf16_linear(W.to(DEV), x.to(DEV), out, bias=bias.to(DEV))
+    assert_bf16_close(out, rbf(x.double() @ W.double().t() + bias.double()), ulps=1, atol=1e-3, what=f"bf16 gemm {M}x{N}x{K}")
+    norm = ops.Norm(2, (1 + 0.1 * torch.randn(K, generator=g)).to(BF).to(DEV), (0.1 * torch.randn(K, generator=g)).to(BF).to(DEV), 1e-5)
+    a, b = torch.empty_like(out), torch.empty_like(out)
+    ops.bf16_linear(W.to(DEV), x.to(DEV), a, norm=norm)  # prefill: stand-alone norm kernel, then the GEMM
+    for m0 in range(0, M, 8):
+        ops.bf16_linear(W.to(DEV), x[m0:m0 + 8].to(DEV), b[m0:m0 + 8], norm=norm)  # decode: fused prologue
+    assert_bf16_close(a, b.float(), ulps=1, atol=2e-3, what="norm + gemm vs fused gemv")
+
+
 # ------------------------------------------------------------------------------------------------ dense bf16
 @pytest.mark.parametrize("N,K", [(64, 128), (100, 768), (64, 4096), (32, 16384), (16, 3072), (8, 32768), (40, 352)])
 @pytest.mark.parametrize("M", [1, 2, 3])

@@ -38,6 +38,8 @@ def main():
     ap.add_argument("--mode", default="w4")
     ap.add_argument("--iters", type=int, default=200)
     ap.add_argument("--group", type=int, default=128)
+    ap.add_argument("--norm", type=int, default=0, help="1: fuse an RMSNorm prologue")
+    ap.add_argument("--stamps", type=int, default=0, help="1: print in-kernel phase stamps of 3 workgroups (diagnostic)")
     args = ap.parse_args()
     cfg = Config.from_name(args.config)
     lib = _hip.load()
@@ -60,26 +62,48 @@ def main():
         if name == "mlp.fc_2":
             continue
         st = _hip.stream()
-        for rows in ((0, 4, 8, 16) if args.mode == "w4" and tune is not None else (0,)):
+        import ctypes as C
+        nw = torch.ones(K, dtype=torch.bfloat16, device=DEV)
+        norm = C.byref(_hip.ParrotNorm(1, nw.data_ptr(), None, 1e-5, 0)) if args.norm else None
+        tune_stream = getattr(lib, "parrot_tune_w4_stream", None)
+        variants = [(0, 0, 0), (1, 2, 1), (1, 2, 2), (1, 2, 4), (1, 4, 1), (1, 4, 2), (1, 3, 2), (1, 6, 2), (1, 8, 1)] if args.mode == "w4" and tune_stream is not None else [(0, 0, 0)]
+        for use_stream, gx, rows in variants:
             if tune is not None:
                 tune(rows)
+            if tune_stream is not None:
+                tune_stream(use_stream, gx)
 
             def call(i):
                 w = bufs[i % copies]
                 w2 = bufs[(i + 1) % copies] if dual else None
                 if args.mode == "w4":
                     rc = lib.parrot_w4_gemv(w.data_ptr(), w2.data_ptr() if dual else None, x.data_ptr(), K, 1, None, None, 0,
-                                            out.data_ptr(), N, N, K, args.group, 3 if dual else 0, st)
+                                            out.data_ptr(), N, N, K, args.group, 3 if dual else 0, norm, st)
                 else:
                     rc = lib.parrot_bf16_gemv(w.view(torch.bfloat16).data_ptr(), w2.view(torch.bfloat16).data_ptr() if dual else None,
-                                              x.data_ptr(), K, 1, None, None, 0, out.data_ptr(), N, N, K, 3 if dual else 0, st)
+                                              x.data_ptr(), K, 1, None, None, 0, out.data_ptr(), N, N, K, 3 if dual else 0, norm, st)
                 assert rc == 0, _hip.last_error()
 
             us = time_loop(call, 20, args.iters)
+            if args.stamps and use_stream == 0:
+                dbg = torch.zeros(24, dtype=torch.int64, device=DEV)
+                lib.parrot_tune_w4_stamps.argtypes = [C.c_void_p]
+                lib.parrot_tune_w4_stamps(dbg.data_ptr())
+                for i in range(3):
+                    call(i)
+                torch.cuda.synchronize()
+                lib.parrot_tune_w4_stamps(None)
+                d = dbg.cpu().view(3, 8).double() * 0.01
+                t0 = float(d[:, 0].min())
+                for b, nm in enumerate(("first wg", "middle wg", "last wg")):
+                    r = d[b]
+                    print(f"    {nm:9s} entry +{float(r[0]) - t0:5.2f}us | x/norm ready {float(r[1] - r[0]):5.2f} | dots {float(r[2] - r[1]):5.2f} | barrier {float(r[3] - r[2]):5.2f} | epilogue {float(r[4] - r[3]):5.2f} | exit at +{float(r[4]) - t0:5.2f}")
             b = algo * (2 if dual else 1)
-            print(f"{name:10s}{'+fc_2' if dual else '     '} N={N:6d} K={K:6d} rows/wg={rows:2d}  {us:7.2f} us/launch  {b / us / 1e3:7.1f} GB/s  ({b / 1e6:.1f} MB)")
+            print(f"{name:10s}{'+fc_2' if dual else '     '} N={N:6d} K={K:6d} stream={use_stream} G={128 * gx:4d} wps={rows}  {us:7.2f} us/launch  {b / us / 1e3:7.1f} GB/s  ({b / 1e6:.1f} MB)")
         if tune is not None:
             tune(0)
+        if tune_stream is not None:
+            tune_stream(1, 0)
         del bufs
 
 
