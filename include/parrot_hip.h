@@ -101,14 +101,15 @@ int parrot_bf16_gemm(const void* W, const void* W2, const void* x, int ldx, int 
 int parrot_w8_quantize_rows(const void* W_bf16, int N, int K, void* CB_int8, void* SCB_f32, void* stream);
 /* activation prep per token row: fp16-round x, mark |x| >= threshold as outliers
  * (kept in 16-bit, zero in the int8 copy), absmax-quantise the rest.
- * xq int8 [M][K]; xout fp32 [M][K] (the outlier values, 0 elsewhere); sca fp32 [M]; nout int32 [M] */
+ * xq int8 [M][K]; xout fp32 [M][K] (the outlier values, 0 elsewhere); sca fp32 [M]; nout int32 [M];
+ * oidx int32 [M][K]: the first nout[m] entries of row m list its outlier columns */
 int parrot_w8_prep_act(const void* x, int ldx, int M, int K, float threshold, void* xq, void* xout,
-                       void* sca, void* nout, const parrot_norm_t* norm, void* stream);
+                       void* sca, void* nout, void* oidx, const parrot_norm_t* norm, void* stream);
 /* out = epilogue(cast_bf16(fp16(fp16(C32*SCA*SCB/127^2 + bias) + fp16(outlier_part)))).
  * For PARROT_EPI_SWIGLU the second weight (fc_2) follows the first in the same buffers:
  * CB holds 2N rows ([fc_1; fc_2]) and SCB 2N scales. */
 int parrot_w8_gemv(const void* CB, const void* SCB, const void* xq, const void* xout, const void* sca,
-                   const void* nout, int M, const void* bias, const void* residual, int ldr, void* out,
+                   const void* nout, const void* oidx, int M, const void* bias, const void* residual, int ldr, void* out,
                    int ldo, int N, int K, int epilogue, void* stream);
 
 /* ---- norms (lit_gpt/rmsnorm.py:17-21; torch.nn.LayerNorm via lit_gpt/config.py:86-92) ---- */
@@ -143,7 +144,7 @@ int parrot_attn_decode(const void* q, int M, const int32_t* pos, const void* k_c
 
 /* Decode step (one new token) of CausalSelfAttention in ONE launch: q/k/v split + RoPE + KV append + attention over
  * slots 0..min(*pos, S-1) + cross-split combine (lit_gpt/model.py:208-247).  qkv: one row; y: [n_head*hs] bf16.
- * workspace as for parrot_attn_decode (M = 1); tickets: n_groups zero-initialised uint32 (re-armed by the kernel). */
+ * workspace as for parrot_attn_decode (M = 1); tickets: n_head zero-initialised uint32 (one per group and chunk of query heads; re-armed by the kernel). */
 int parrot_attn_fused_decode(const void* qkv, const void* rope_cos, const void* rope_sin, int n_elem,
                              const int32_t* pos, int n_groups, int q_per_kv, int hs, int S, int nsplit,
                              void* workspace, void* tickets, void* k_cache, void* v_cache, void* y,

@@ -242,6 +242,7 @@ attn_fused_decode_kernel(const bf16_t* __restrict__ qkv, const __half* __restric
     __shared__ int sh_last;
 
     const int g = blockIdx.x, split = blockIdx.y;
+    const int h0 = blockIdx.z * HQ;  // this workgroup's chunk of the group's query heads (GQA: chunks run in parallel)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int sub = lane / LPR, dl = lane % LPR;
     const int n_head = n_groups * q_per_kv;
@@ -304,7 +305,7 @@ attn_fused_decode_kernel(const bf16_t* __restrict__ qkv, const __half* __restric
     }
     __syncthreads();
     // ---- KV append by the workgroup that owns the new slot
-    if (slot_new >= s_begin && slot_new < s_begin + per && threadIdx.x < 2 * LPR) {
+    if (blockIdx.z == 0 && slot_new >= s_begin && slot_new < s_begin + per && threadIdx.x < 2 * LPR) {
         const int which = threadIdx.x / LPR, c = threadIdx.x % LPR;
         bf16_t* dst = (which ? v_cache : k_cache) + ((int64_t)g * S + slot_new) * HS;
         reinterpret_cast<uint4*>(dst)[c] = reinterpret_cast<const uint4*>(sh_kv[which])[c];
@@ -312,7 +313,7 @@ attn_fused_decode_kernel(const bf16_t* __restrict__ qkv, const __half* __restric
     const uint4 knew = reinterpret_cast<const uint4*>(sh_kv[0])[dl];
     const uint4 vnew = reinterpret_cast<const uint4*>(sh_kv[1])[dl];
 
-    for (int h0 = 0; h0 < q_per_kv; h0 += HQ) {
+    {
         float qf[HQ][8];
         float mrun[HQ], lrun[HQ], acc[HQ][8];
 #pragma unroll
@@ -324,11 +325,6 @@ attn_fused_decode_kernel(const bf16_t* __restrict__ qkv, const __half* __restric
             lrun[hh] = 0.f;
 #pragma unroll
             for (int e = 0; e < 8; ++e) acc[hh][e] = 0.f;
-        }
-        if (h0 != 0 && s_first < s_end) {  // later head passes (GQA) re-read the rows, now from L2
-            const int sc = min(s_first + sub, s_end - 1);
-            kv_cur = kc[(int64_t)sc * LPR + dl];
-            vv_cur = vc[(int64_t)sc * LPR + dl];
         }
         for (int s0 = s_first; s0 < s_end; s0 += STRIDE) {
             // software pipeline: request the next rows before working on the current ones
@@ -418,14 +414,15 @@ attn_fused_decode_kernel(const bf16_t* __restrict__ qkv, const __half* __restric
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every storing wave drains its write-through stores
     __syncthreads();
     if (threadIdx.x == 0) {
-        const unsigned int t = __hip_atomic_fetch_add(&tickets[g], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned int t = __hip_atomic_fetch_add(&tickets[g * gridDim.z + blockIdx.z], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         sh_last = (t == (unsigned int)(nsplit - 1));
-        if (sh_last) __hip_atomic_store(&tickets[g], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // re-arm
+        if (sh_last) __hip_atomic_store(&tickets[g * gridDim.z + blockIdx.z], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // re-arm
     }
     __syncthreads();
     if (!sh_last) return;
-    for (int idx = threadIdx.x; idx < q_per_kv * HS; idx += kAttnWaves * 64) {
-        const int hq = idx / HS, d = idx % HS;
+    for (int idx = threadIdx.x; idx < HQ * HS; idx += kAttnWaves * 64) {
+        const int hq = h0 + idx / HS, d = idx % HS;
+        if (hq >= q_per_kv) continue;
         const int head = g * q_per_kv + hq;
         const float* p = ws + (int64_t)head * nsplit * (HS + 2);
         float mx = -INFINITY;
@@ -445,7 +442,8 @@ template <int HS>
 static int attn_fused_launch(const void* qkv, const void* cosp, const void* sinp, int n_elem, const int32_t* pos,
                              void* k_cache, void* v_cache, int n_groups, int q_per_kv, int S, int nsplit, void* ws,
                              void* tickets, void* y, hipStream_t st) {
-    const dim3 grid(n_groups, nsplit), block(kAttnWaves * 64);
+    const int hq = q_per_kv == 1 ? 1 : (q_per_kv == 2 ? 2 : 4);
+    const dim3 grid(n_groups, nsplit, (q_per_kv + hq - 1) / hq), block(kAttnWaves * 64);
 #define PARROT_FUSED_GO(HQV)                                                                                          \
     return launch(K_ATTN_FUSED, attn_fused_decode_kernel<HS, HQV>, grid, block, 0, st, (const bf16_t*)qkv,            \
                   (const __half*)cosp, (const __half*)sinp, n_elem, pos, (bf16_t*)k_cache, (bf16_t*)v_cache, n_groups, \

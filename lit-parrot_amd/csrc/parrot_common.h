@@ -148,6 +148,15 @@ __device__ __forceinline__ float wave_sum_to_lane63(float v) {
     v += dpp0<0x143, 0xC>(v);  // row_bcast31 into rows 2 and 3
     return v;
 }
+__device__ __forceinline__ int wave_sum_i32_to_lane63(int v) {
+    v += __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xF, 0xF, true);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xF, 0xF, true);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x141, 0xF, 0xF, true);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x140, 0xF, 0xF, true);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xA, 0xF, true);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xC, 0xF, true);
+    return v;
+}
 __device__ __forceinline__ float wave_max(float v) {
 #pragma unroll
     for (int off = 32; off >= 1; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 64));

@@ -13,6 +13,8 @@
 // 16+4i is k = 8d+2i+1, so that ((dword >> 4i) & 0x000F000F) | 0x43004300 is the bf16 pair
 // {128+q[8d+2i], 128+q[8d+2i+1]}, the operand of v_dot2c_f32_bf16 against the natural bf16 pair of x.
 // The +128 bias is removed with the per-lane sum of x: s * (sum x*(128+q) - (128+z) * sum x).
+#include <stdlib.h>
+
 #include "parrot_common.h"
 #include "w4_plan.h"
 
@@ -461,10 +463,21 @@ static int g_wps_override = 0;  // tuning hook (tools/microbench.py): row groups
 
 // row groups per workgroup: aim at ~640 workgroups per launch, bounded by the waves the build allows
 static int pick_wps(int N, int RU, int nslabs, int maxw, bool norm) {
+    static int env_wps = -1;  // PARROT_W4_WPS: experiment hook
+    if (env_wps < 0) {
+        const char* e = getenv("PARROT_W4_WPS");
+        env_wps = e ? atoi(e) : 0;
+    }
+    if (env_wps > 0 && g_wps_override == 0) {
+        int w = env_wps;
+        if (w * nslabs > maxw) w = maxw / nslabs;
+        return w < 1 ? 1 : w;
+    }
     int cap = maxw / nslabs;
     if (cap < 1) cap = 1;
     int wps = g_wps_override > 0 ? g_wps_override : (int)((N + (int64_t)RU * 320) / ((int64_t)RU * 640));
     if (norm && wps < 2 && cap >= 2 && g_wps_override == 0) wps = 2;  // share the norm over at least two row groups
+    if (wps > 2 && g_wps_override == 0) wps = 2;  // measured in the decode pipeline: 2 row groups per workgroup is the sweet spot
     if (wps < 1) wps = 1;
     if (wps > cap) wps = cap;
     return wps;
@@ -489,7 +502,7 @@ static int w4_gemv_launch_v(const void* packed, const void* packed2, const void*
                   (const bf16_t*)residual, ldr, (bf16_t*)out, ldo, N, K, wps, epi, na, plan);
 }
 
-static int g_use_stream = 1;  // tuning hook: 0 = burst kernel for M = 1 as well
+static int g_use_stream = 0;  // the pipelined kernel measured no faster than the burst kernel (tools/microbench.py); kept selectable
 
 template <bool DUAL, int RU, int MAXW>
 static int w4_stream_launch(const void* packed, const void* packed2, const void* x, const void* bias, const void* residual,

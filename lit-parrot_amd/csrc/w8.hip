@@ -40,65 +40,132 @@ w8_quantize_rows_kernel(const bf16_t* __restrict__ W, int K, int8_t* __restrict_
     if (threadIdx.x == 0) SCB[blockIdx.x] = mx;
 }
 
-// one workgroup per token row; optional fused norm of the row (the quantised copy is taken from the normalised values)
-__global__ void __launch_bounds__(256)
+// One workgroup (1024 threads) per token row, one pass: every thread keeps up to kPrepV 16-byte chunks of the row in
+// registers (K <= 1024 * 8 * kPrepV), so the row is read once for: optional fused norm -> fp16 cast -> outlier split ->
+// row absmax -> int8.  The outlier columns are also written as a compact, deterministic index list (thread-major order)
+// so that the GEMV's mixed-precision part touches only those columns.
+constexpr int kPrepThreads = 1024;
+constexpr int kPrepV = 4;
+
+__device__ __forceinline__ float block_max_1024(float v, float* sh) {
+    v = wave_max(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+    __syncthreads();
+    float t = sh[0];
+#pragma unroll
+    for (int i = 1; i < kPrepThreads / 64; ++i) t = fmaxf(t, sh[i]);
+    return t;
+}
+
+__global__ void __launch_bounds__(kPrepThreads)
 w8_prep_act_kernel(const bf16_t* __restrict__ x, int ldx, int K, float threshold, int8_t* __restrict__ xq,
-                   float* __restrict__ xout, float* __restrict__ sca, int32_t* __restrict__ nout, NormArgs na) {
-    __shared__ float sh[4];
+                   float* __restrict__ xout, float* __restrict__ sca, int32_t* __restrict__ nout,
+                   int32_t* __restrict__ oidx, NormArgs na) {
+    __shared__ float sh[16];
     __shared__ float stat[16];
-    __shared__ int cnt;
+    __shared__ int scan[kPrepThreads / 64];
     const int m = blockIdx.x;
-    const bf16_t* xr = x + (int64_t)m * ldx;
-    if (threadIdx.x == 0) cnt = 0;
+    const int chunks = K >> 3;
+    const uint4* xr = reinterpret_cast<const uint4*>(x + (int64_t)m * ldx);
+    float a[kPrepV][8];
+    // ---- load (+ fused norm) -> fp16-rounded values in registers
+    uint32_t raw[kPrepV][4];
+#pragma unroll
+    for (int i = 0; i < kPrepV; ++i) {
+        const int c = threadIdx.x + i * kPrepThreads;
+        const uint4 v = c < chunks ? xr[c] : make_uint4(0, 0, 0, 0);
+        raw[i][0] = v.x; raw[i][1] = v.y; raw[i][2] = v.z; raw[i][3] = v.w;
+    }
     float mean = 0.f, r = 1.f;
     if (na.kind != 0) {
         float s1 = 0.f;
-        for (int k = threadIdx.x; k < K; k += 256) {
-            const float a = bf2f(xr[k]);
-            s1 += na.kind == 1 ? rbf(a * a) : a;
-        }
-        s1 = block_sum_waves(s1, stat, 4);
+#pragma unroll
+        for (int i = 0; i < kPrepV; ++i)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) s1 += norm_stat1(raw[i][q], na.kind);
+        s1 = block_sum_waves(s1, stat, kPrepThreads / 64);
         if (na.kind == 2) {
             mean = s1 / (float)K;
             float s2 = 0.f;
-            for (int k = threadIdx.x; k < K; k += 256) {
-                const float a = bf2f(xr[k]) - mean;
-                s2 += a * a;
-            }
-            r = norm_scale(na, block_sum_waves(s2, stat, 4));
+#pragma unroll
+            for (int i = 0; i < kPrepV; ++i)
+                if (threadIdx.x + i * kPrepThreads < chunks)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) s2 += norm_stat2(raw[i][q], mean);
+            r = norm_scale(na, block_sum_waves(s2, stat, kPrepThreads / 64));
         } else {
             r = norm_scale(na, s1);
         }
     }
-    auto value = [&](int k) -> float {
-        float a = bf2f(xr[k]);
-        if (na.kind == 1) {
-            a = rbf(bf2f(na.weight[k]) * rbf(a * r));
-        } else if (na.kind == 2) {
-            a = rbf((a - mean) * r * bf2f(na.weight[k]) + (na.bias ? bf2f(na.bias[k]) : 0.f));
-        }
-        return rhalf(a);
-    };
     float mx = 0.f;
-    for (int k = threadIdx.x; k < K; k += 256) {
-        const float a = value(k);
-        if (!(threshold > 0.f && fabsf(a) >= threshold)) mx = fmaxf(mx, fabsf(a));
-    }
-    mx = block_max_256(mx, sh);
-    const float inv = mx > 0.f ? __fdiv_rn(127.0f, mx) : 0.f;  // correctly rounded, like the host oracle
     int local = 0;
-    for (int k = threadIdx.x; k < K; k += 256) {
-        const float a = value(k);
-        const bool outlier = threshold > 0.f && fabsf(a) >= threshold;
-        xq[(int64_t)m * K + k] = outlier ? (int8_t)0 : (int8_t)rintf(__fmul_rn(a, inv));
-        xout[(int64_t)m * K + k] = outlier ? a : 0.f;
-        local += outlier ? 1 : 0;
+#pragma unroll
+    for (int i = 0; i < kPrepV; ++i) {
+        const int c = threadIdx.x + i * kPrepThreads;
+        const bool ok = c < chunks;
+        uint32_t nrm[4] = {raw[i][0], raw[i][1], raw[i][2], raw[i][3]};
+        if (na.kind != 0 && ok) {
+            const uint4 wv = reinterpret_cast<const uint4*>(na.weight)[c];
+            uint4 bv = make_uint4(0, 0, 0, 0);
+            if (na.kind == 2 && na.bias != nullptr) bv = reinterpret_cast<const uint4*>(na.bias)[c];
+            const uint32_t ww[4] = {wv.x, wv.y, wv.z, wv.w}, bb[4] = {bv.x, bv.y, bv.z, bv.w};
+#pragma unroll
+            for (int q = 0; q < 4; ++q) nrm[q] = norm_apply(raw[i][q], ww[q], bb[q], na.kind, mean, r);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            a[i][2 * q] = rhalf(bflo(nrm[q]));
+            a[i][2 * q + 1] = rhalf(bfhi(nrm[q]));
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const bool outlier = ok && threshold > 0.f && fabsf(a[i][e]) >= threshold;
+            if (ok && !outlier) mx = fmaxf(mx, fabsf(a[i][e]));
+            local += outlier ? 1 : 0;
+        }
     }
-    if (local) atomicAdd(&cnt, local);
+    mx = block_max_1024(mx, sh);
+    const float inv = mx > 0.f ? __fdiv_rn(127.0f, mx) : 0.f;  // correctly rounded, like the host oracle
+    // ---- exclusive scan of the outlier counts (wave prefix + LDS over the 16 waves) -> slots in the index list
+    int incl = local;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const int o = __shfl_up(incl, off, 64);
+        if ((int)(threadIdx.x & 63) >= off) incl += o;
+    }
+    if ((threadIdx.x & 63) == 63) scan[threadIdx.x >> 6] = incl;
     __syncthreads();
+    int base = 0, total = 0;
+#pragma unroll
+    for (int w = 0; w < kPrepThreads / 64; ++w) {
+        if (w < (int)(threadIdx.x >> 6)) base += scan[w];
+        total += scan[w];
+    }
+    int slot = base + incl - local;
+#pragma unroll
+    for (int i = 0; i < kPrepV; ++i) {
+        const int c = threadIdx.x + i * kPrepThreads;
+        if (c < chunks) {
+            uint32_t q8[2] = {0, 0};
+            float o8[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const bool outlier = threshold > 0.f && fabsf(a[i][e]) >= threshold;
+                const int qv = outlier ? 0 : (int)rintf(__fmul_rn(a[i][e], inv));
+                q8[e >> 2] |= (uint32_t)(qv & 0xff) << (8 * (e & 3));
+                o8[e] = outlier ? a[i][e] : 0.f;
+                if (outlier) oidx[(int64_t)m * K + slot++] = c * 8 + e;
+            }
+            *reinterpret_cast<uint2*>(xq + (int64_t)m * K + (int64_t)c * 8) = make_uint2(q8[0], q8[1]);
+            float4* op = reinterpret_cast<float4*>(xout + (int64_t)m * K + (int64_t)c * 8);
+            op[0] = make_float4(o8[0], o8[1], o8[2], o8[3]);
+            op[1] = make_float4(o8[4], o8[5], o8[6], o8[7]);
+        }
+    }
     if (threadIdx.x == 0) {
         sca[m] = mx;
-        nout[m] = cnt;
+        nout[m] = total;
     }
 }
 
@@ -110,8 +177,9 @@ template <bool DUAL, int J>
 __global__ void __launch_bounds__(512)
 w8_gemv_kernel(const uint4* __restrict__ CB, const uint4* __restrict__ CB2, const float* __restrict__ SCB,
                const float* __restrict__ SCB2, const int8_t* __restrict__ xq, const float* __restrict__ xout,
-               const float* __restrict__ sca, const int32_t* __restrict__ nout, const bf16_t* __restrict__ bias,
-               const bf16_t* residual, int ldr, bf16_t* out, int ldo, int N, int K, int rows_per_wg, int epi, int nslabs) {
+               const float* __restrict__ sca, const int32_t* __restrict__ nout, const int32_t* __restrict__ oidx,
+               const bf16_t* __restrict__ bias, const bf16_t* residual, int ldr, bf16_t* out, int ldo, int N, int K,
+               int rows_per_wg, int epi, int nslabs) {
     constexpr int NW = DUAL ? 2 : 1;
     __shared__ int red[kW8MaxSlabs][kW8MaxRows * NW];
     const int m = blockIdx.y;
@@ -158,9 +226,8 @@ w8_gemv_kernel(const uint4* __restrict__ CB, const uint4* __restrict__ CB2, cons
                     p = __builtin_amdgcn_sdot4((int)w[q][u][j].z, xr[j][2], p, false);
                     p = __builtin_amdgcn_sdot4((int)w[q][u][j].w, xr[j][3], p, false);
                 }
-#pragma unroll
-                for (int off = 32; off >= 1; off >>= 1) p += __shfl_xor(p, off, 64);
-                if (lane == 0) red[wave][(r0 - r_begin + u) * NW + q] = p;
+                p = wave_sum_i32_to_lane63(p);
+                if (lane == 63) red[wave][(r0 - r_begin + u) * NW + q] = p;
             }
     }
     __syncthreads();
@@ -178,12 +245,12 @@ w8_gemv_kernel(const uint4* __restrict__ CB, const uint4* __restrict__ CB2, cons
             const float b = (bias != nullptr && q == 0) ? bf2f(bias[col]) : 0.f;
             // separately rounded fp32 products and sum (no FMA), the order mm_dequant uses
             float v = rhalf(__fadd_rn(__fmul_rn(__fmul_rn(__fmul_rn((float)c32, kMmDequant), sa), scb), b));
-            if (no > 0) {  // mixed-precision decomposition: scan the row for the outlier columns
+            if (no > 0) {  // mixed-precision decomposition over the compact list of outlier columns
                 const int8_t* wrow = reinterpret_cast<const int8_t*>(q ? CB2 : CB) + (int64_t)col * K;
                 float o = 0.f;
-                for (int k = 0; k < K; ++k) {
-                    const float a = xout[(int64_t)m * K + k];
-                    if (a != 0.f) o += a * rhalf(__fdiv_rn(__fmul_rn((float)wrow[k], scb), 127.0f));
+                for (int t = 0; t < no; ++t) {
+                    const int k = oidx[(int64_t)m * K + t];
+                    o += xout[(int64_t)m * K + k] * rhalf(__fdiv_rn(__fmul_rn((float)wrow[k], scb), 127.0f));
                 }
                 v = rhalf(v + rhalf(o));
             }
@@ -196,19 +263,19 @@ w8_gemv_kernel(const uint4* __restrict__ CB, const uint4* __restrict__ CB2, cons
 
 template <int J>
 static int w8_launch(const void* CB, const void* CB2, const void* SCB, const void* SCB2, const void* xq, const void* xout,
-                     const void* sca, const void* nout, int M, const void* bias, const void* residual, int ldr, void* out,
+                     const void* sca, const void* nout, const void* oidx, int M, const void* bias, const void* residual, int ldr, void* out,
                      int ldo, int N, int K, int epi, int nslabs, hipStream_t st) {
     const int R = N >= 16 * 2048 ? 16 : (N >= 8 * 1024 ? 8 : 4);
     const dim3 grid((N + R - 1) / R, M), block(64 * nslabs);
     if (epi == PARROT_EPI_SWIGLU)
         return launch(K_W8_GEMV, w8_gemv_kernel<true, J>, grid, block, 0, st, (const uint4*)CB, (const uint4*)CB2,
                       (const float*)SCB, (const float*)SCB2, (const int8_t*)xq, (const float*)xout, (const float*)sca,
-                      (const int32_t*)nout, (const bf16_t*)bias, (const bf16_t*)residual, ldr, (bf16_t*)out, ldo, N, K, R,
-                      epi, nslabs);
+                      (const int32_t*)nout, (const int32_t*)oidx, (const bf16_t*)bias, (const bf16_t*)residual, ldr, (bf16_t*)out, ldo,
+                      N, K, R, epi, nslabs);
     return launch(K_W8_GEMV, w8_gemv_kernel<false, J>, grid, block, 0, st, (const uint4*)CB, (const uint4*)CB2,
                   (const float*)SCB, (const float*)SCB2, (const int8_t*)xq, (const float*)xout, (const float*)sca,
-                  (const int32_t*)nout, (const bf16_t*)bias, (const bf16_t*)residual, ldr, (bf16_t*)out, ldo, N, K, R, epi,
-                  nslabs);
+                  (const int32_t*)nout, (const int32_t*)oidx, (const bf16_t*)bias, (const bf16_t*)residual, ldr, (bf16_t*)out, ldo, N,
+                  K, R, epi, nslabs);
 }
 
 }  // namespace parrot
@@ -225,22 +292,24 @@ int parrot_w8_quantize_rows(const void* W_bf16, int N, int K, void* CB_int8, voi
 }
 
 int parrot_w8_prep_act(const void* x, int ldx, int M, int K, float threshold, void* xq, void* xout, void* sca, void* nout,
-                       const parrot_norm_t* norm, void* stream) {
-    PARROT_REQUIRE(x && xq && xout && sca && nout, "w8_prep_act: null pointer");
+                       void* oidx, const parrot_norm_t* norm, void* stream) {
+    PARROT_REQUIRE(x && xq && xout && sca && nout && oidx, "w8_prep_act: null pointer");
     PARROT_REQUIRE(M >= 1 && K >= 1 && ldx >= K, "w8_prep_act: bad shape M=%d K=%d ldx=%d", M, K, ldx);
+    PARROT_UNSUPPORTED(K % 8 == 0 && ldx % 8 == 0 && K <= kPrepThreads * 8 * kPrepV && aligned16(x),
+                       "w8_prep_act: K=%d must be a multiple of 8 and <= %d, rows 16-byte aligned", K, kPrepThreads * 8 * kPrepV);
     NormArgs na;
     const int rc = make_norm_args(norm, K, &na);
     if (rc != PARROT_OK) return rc;
-    return launch(K_W8_PREP_ACT, w8_prep_act_kernel, dim3(M), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, ldx, K,
-                  threshold, (int8_t*)xq, (float*)xout, (float*)sca, (int32_t*)nout, na);
+    return launch(K_W8_PREP_ACT, w8_prep_act_kernel, dim3(M), dim3(kPrepThreads), 0, (hipStream_t)stream, (const bf16_t*)x, ldx,
+                  K, threshold, (int8_t*)xq, (float*)xout, (float*)sca, (int32_t*)nout, (int32_t*)oidx, na);
 }
 
 // CB / SCB may be followed by a second weight for the SWIGLU epilogue: pass them concatenated as
 // CB = [CB1; CB2] is NOT assumed; the second weight is addressed as CB + N*K and SCB + N (fc_1 then fc_2 rows).
 int parrot_w8_gemv(const void* CB, const void* SCB, const void* xq, const void* xout, const void* sca, const void* nout,
-                   int M, const void* bias, const void* residual, int ldr, void* out, int ldo, int N, int K, int epilogue,
+                   const void* oidx, int M, const void* bias, const void* residual, int ldr, void* out, int ldo, int N, int K, int epilogue,
                    void* stream) {
-    PARROT_REQUIRE(CB && SCB && xq && xout && sca && nout && out, "w8_gemv: null pointer");
+    PARROT_REQUIRE(CB && SCB && xq && xout && sca && nout && oidx && out, "w8_gemv: null pointer");
     PARROT_REQUIRE(M >= 1 && M <= 65535 && N >= 1 && K >= 1, "w8_gemv: bad shape M=%d N=%d K=%d", M, N, K);
     PARROT_REQUIRE(epilogue >= PARROT_EPI_NONE && epilogue <= PARROT_EPI_SWIGLU, "w8_gemv: unknown epilogue %d", epilogue);
     PARROT_REQUIRE((epilogue == PARROT_EPI_RESIDUAL) == (residual != nullptr), "w8_gemv: residual iff RESIDUAL epilogue");
@@ -259,9 +328,9 @@ int parrot_w8_gemv(const void* CB, const void* SCB, const void* xq, const void* 
     const int per_slab = (chunks + nslabs - 1) / nslabs;
     const int jn = (per_slab + 63) / 64;
     hipStream_t st = (hipStream_t)stream;
-    if (jn <= 1) return w8_launch<1>(CB, CB2, SCB, SCB2, xq, xout, sca, nout, M, bias, residual, ldr, out, ldo, N, K, epilogue, nslabs, st);
-    if (jn <= 2) return w8_launch<2>(CB, CB2, SCB, SCB2, xq, xout, sca, nout, M, bias, residual, ldr, out, ldo, N, K, epilogue, nslabs, st);
-    return w8_launch<4>(CB, CB2, SCB, SCB2, xq, xout, sca, nout, M, bias, residual, ldr, out, ldo, N, K, epilogue, nslabs, st);
+    if (jn <= 1) return w8_launch<1>(CB, CB2, SCB, SCB2, xq, xout, sca, nout, oidx, M, bias, residual, ldr, out, ldo, N, K, epilogue, nslabs, st);
+    if (jn <= 2) return w8_launch<2>(CB, CB2, SCB, SCB2, xq, xout, sca, nout, oidx, M, bias, residual, ldr, out, ldo, N, K, epilogue, nslabs, st);
+    return w8_launch<4>(CB, CB2, SCB, SCB2, xq, xout, sca, nout, oidx, M, bias, residual, ldr, out, ldo, N, K, epilogue, nslabs, st);
 }
 
 }  // extern "C"

@@ -57,7 +57,7 @@ class Workspace:
         self.h = buf(c.intermediate_size)
         self.logits = buf(c.padded_vocab_size, lm_rows)
         self.zero_pos = torch.zeros((1,), dtype=torch.int32, device=device)
-        self.tickets = torch.zeros((c.n_query_groups,), dtype=torch.int32, device=device)  # fused attention arrival counters
+        self.tickets = torch.zeros((c.n_head,), dtype=torch.int32, device=device)  # fused attention arrival counters
         self._attn_ws = {}
 
     def attn_ws(self, config: Config, nsplit: int) -> torch.Tensor:
@@ -181,7 +181,7 @@ class GPT(nn.Module):
         """
         M = ws.M
         ops.embedding(self.transformer.wte.weight.data, tokens, tok_pos, M, ws.x)
-        nsplit = ops.attn_nsplit(self.config.n_query_groups, S)
+        nsplit = ops.attn_nsplit(self.config.n_query_groups, S, self.config.q_per_kv)
         for block, (kc, vc) in zip(self.transformer.h, caches):
             block.run_rows(ws, pos, S, kc, vc, rope, nsplit, rope_local)
         last = ws.x if ws.lm_rows == M else ws.x[M - 1:M]

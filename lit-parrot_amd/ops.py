@@ -157,6 +157,7 @@ class W8Act:
         self.xout = torch.empty((M, K), dtype=torch.float32, device=device)
         self.sca = torch.empty((M,), dtype=torch.float32, device=device)
         self.nout = torch.empty((M,), dtype=torch.int32, device=device)
+        self.oidx = torch.empty((M, K), dtype=torch.int32, device=device)  # compact outlier column list per row
 
 
 def w8_prep_act(x: torch.Tensor, threshold: float, act: W8Act, norm: Optional[Norm] = None) -> W8Act:
@@ -164,14 +165,14 @@ def w8_prep_act(x: torch.Tensor, threshold: float, act: W8Act, norm: Optional[No
     M, K = x.shape
     assert (M, K) == (act.M, act.K)
     check(_hip.load().parrot_w8_prep_act(ptr(x), x.stride(0), M, K, float(threshold), ptr(act.xq), ptr(act.xout),
-                                         ptr(act.sca), ptr(act.nout), _norm_arg(norm, K), stream()), "parrot_w8_prep_act")
+                                         ptr(act.sca), ptr(act.nout), ptr(act.oidx), _norm_arg(norm, K), stream()), "parrot_w8_prep_act")
     return act
 
 
 def w8_linear(CB: torch.Tensor, SCB: torch.Tensor, N: int, K: int, act: W8Act, out: torch.Tensor, *, bias=None,
               epilogue=EPI_NONE, residual=None) -> torch.Tensor:
     _rows(out, "w8_linear")
-    check(_hip.load().parrot_w8_gemv(ptr(CB), ptr(SCB), ptr(act.xq), ptr(act.xout), ptr(act.sca), ptr(act.nout), act.M,
+    check(_hip.load().parrot_w8_gemv(ptr(CB), ptr(SCB), ptr(act.xq), ptr(act.xout), ptr(act.sca), ptr(act.nout), ptr(act.oidx), act.M,
                                      ptr(_opt_vec(bias, N, "bias")), ptr(residual),
                                      residual.stride(0) if residual is not None else 0, ptr(out), out.stride(0), N, K,
                                      epilogue, stream()), "parrot_w8_gemv")
@@ -194,10 +195,11 @@ def rope_kvappend(qkv: torch.Tensor, cos: torch.Tensor, sin: torch.Tensor, n_ele
                                                ptr(v_cache), stream()), "parrot_qkv_rope_kvappend")
 
 
-def attn_nsplit(n_groups: int, S: int) -> int:
+def attn_nsplit(n_groups: int, S: int, q_per_kv: int = 1) -> int:
     """Sequence splits of the decode-attention kernel: about 32 keys per workgroup (two row batches per wave at
-    head size 128), bounded by ~1024 workgroups per launch and 64 splits."""
-    return max(1, min(S // 32, max(1, 1024 // n_groups), 64))
+    head size 128), bounded by ~1024 workgroups per launch (groups x head chunks x splits) and 64 splits."""
+    chunks = (q_per_kv + 3) // 4 if q_per_kv > 2 else 1
+    return max(1, min(S // 32, max(1, 1024 // (n_groups * chunks)), 64))
 
 
 def attn_workspace(M: int, n_head: int, hs: int, nsplit: int, device) -> torch.Tensor:
@@ -219,7 +221,7 @@ def attn_fused_decode(qkv: torch.Tensor, cos: torch.Tensor, sin: torch.Tensor, n
                       nsplit: int, workspace: torch.Tensor, tickets: torch.Tensor, y: torch.Tensor) -> torch.Tensor:
     """Single new token: split + RoPE + KV append + attention + combine in one launch."""
     _rows(qkv, "attn_fused_decode"), _rows(y, "attn_fused_decode")
-    if qkv.shape[0] != 1 or tickets.dtype != torch.int32 or tickets.numel() < n_groups:
+    if qkv.shape[0] != 1 or tickets.dtype != torch.int32 or tickets.numel() < n_groups * q_per_kv:
         raise ParrotHipError("attn_fused_decode: one row, int32 tickets[n_groups] expected")
     check(_hip.load().parrot_attn_fused_decode(ptr(qkv), ptr(cos), ptr(sin), n_elem, ptr(pos), n_groups, q_per_kv, hs, S,
                                                nsplit, ptr(workspace), ptr(tickets), ptr(k_cache), ptr(v_cache), ptr(y),

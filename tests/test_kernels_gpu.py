@@ -442,7 +442,7 @@ def test_fused_decode_attention_equals_the_three_kernel_path(n_groups, q_per_kv,
     q = torch.empty((1, n_head * hs), dtype=BF, device=DEV)
     y1, y2 = torch.empty_like(q), torch.empty_like(q)
     ws1, ws2 = ops.attn_workspace(1, n_head, hs, nsplit, DEV), ops.attn_workspace(1, n_head, hs, nsplit, DEV)
-    tickets = torch.zeros((n_groups,), dtype=torch.int32, device=DEV)
+    tickets = torch.zeros((n_head,), dtype=torch.int32, device=DEV)
     for pos in list(range(0, 12)) + list(range(S - 3, S + 9)):
         qkv = torch.randn(1, width, generator=g).to(BF).to(DEV)
         pos_d = torch.tensor([pos], dtype=torch.int32, device=DEV)
