@@ -268,7 +268,10 @@ def main() -> None:
                           "frac": step_gbs / HBM_PEAK_GBS, "bytes_per_token": w_bytes + kv_bytes,
                           "weight_bytes": w_bytes, "kv_bytes_mean_context": kv_bytes},
         "kernels": kernels,
+        # the reference's own definition (generate/base.py:239-255): new tokens / wall time INCLUDING the prefill
+        "reference_definition_tokens_per_s": (args.warmup + args.steps + 1) / (t_pre + (args.warmup + args.steps) * ms_per_step * 1e-3),
         "prefill_ms": t_pre * 1e3,
+        "prefill_tokens_per_s": T / t_pre,
         "build_s": t_build,
     }
     if rank == 0:

@@ -22,7 +22,7 @@ namespace parrot {
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
 typedef __attribute__((ext_vector_type(16))) float f32x16_t;
 
-constexpr int GBM = 128, GBN = 128, GBK = 32;
+constexpr int GBK = 32;  // K-tile; the M x N tile is a template parameter (128 x 128 for long prompts, 64 x 64 to fill the chip on short ones)
 constexpr int GLD = 40;  // LDS row stride in bf16 elements (80 B)
 
 // sum of the activations of every (row, quantisation group): xsum[m][g] = sum_{k in group g} x[m][k]
@@ -41,13 +41,15 @@ gemm_xsum_kernel(const bf16_t* __restrict__ x, int ldx, int M, int K, int G, int
     xsum[t] = s;
 }
 
-template <bool W4>
+template <bool W4, int GBM, int GBN>
 __global__ void __launch_bounds__(256)
 gemm_kernel(const bf16_t* __restrict__ A, int lda, int M, const void* __restrict__ Wv, const void* __restrict__ W2v, int N,
             int K, const float* __restrict__ xsum, const bf16_t* __restrict__ bias, const bf16_t* residual, int ldr,
-            bf16_t* out, int ldo, int epi, W4Plan plan) {
-    __shared__ __attribute__((aligned(16))) bf16_t As[GBM * GLD];
-    __shared__ __attribute__((aligned(16))) bf16_t Bs[GBN * GLD];
+            bf16_t* out, int ldo, int epi, int xs_lds, W4Plan plan) {
+    // two LDS stages: the global loads of K-tile t+1 are in flight (registers) while tile t is multiplied, one barrier per tile
+    __shared__ __attribute__((aligned(16))) bf16_t As[2][GBM * GLD];
+    __shared__ __attribute__((aligned(16))) bf16_t Bs[2][GBN * GLD];
+    extern __shared__ __attribute__((aligned(16))) unsigned char gemm_smem[];  // int4: xsum of this tile's rows [GBM][ngroups]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int m0 = blockIdx.y * GBM, n0 = blockIdx.x * GBN;
@@ -55,109 +57,148 @@ gemm_kernel(const bf16_t* __restrict__ A, int lda, int M, const void* __restrict
     const int ktiles = K / GBK;
     const int Gs = W4 ? plan.Gs : ktiles;  // K-tiles per quantisation group
     const int ngroups = W4 ? plan.ngroups : 1;
+    constexpr int IM = GBM / 64, JN = GBN / 64;  // 32x32 MFMA tiles per wave: each wave owns (GBM/2) x (GBN/2)
+    constexpr int AIT = GBM / 64;                // 16-byte A pieces per thread per K-tile
+    constexpr int BIT = W4 ? (GBN / 64) : (GBN / 64);  // bf16: 16-byte pieces; int4: one dword (8 weights) per piece
 
-    f32x16_t total[2][2];
-    uint32_t gate[2][2][8];  // SwiGLU: bf16(silu(bf16(fc_1))) of the first pass, packed
+    float* xs_l = reinterpret_cast<float*>(gemm_smem);
+    if (W4 && xs_lds) {
+        for (int i = tid; i < GBM * ngroups; i += 256) {
+            const int64_t gm = min(m0 + i / ngroups, M - 1);
+            xs_l[i] = xsum[gm * ngroups + i % ngroups];
+        }
+    }
+
+    f32x16_t total[IM][JN];
+    uint32_t gate[IM][JN][8];  // SwiGLU: bf16(silu(bf16(fc_1))) of the first pass, packed
     const int npass = (epi == PARROT_EPI_SWIGLU) ? 2 : 1;
 
     for (int pass = 0; pass < npass; ++pass) {
         const void* Wp = pass ? W2v : Wv;
-        f32x16_t acc[2][2];
+        f32x16_t acc[IM][JN];
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < IM; ++i)
 #pragma unroll
-            for (int jn = 0; jn < 2; ++jn)
+            for (int jn = 0; jn < JN; ++jn)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     acc[i][jn][r] = 0.f;
                     total[i][jn][r] = 0.f;
                 }
+        uint4 ra[AIT];
+        uint4 rb[BIT];    // bf16 weights
+        uint32_t rq[BIT];  // int4 weights: 8 nibbles each
         int slab = 0;
-        for (int kt = 0; kt < ktiles; ++kt) {
-            // ---- stage the K-tile: A rows (activations) and B rows (weights), 16-byte pieces
+        // global -> registers for K-tile kt
+        auto fetch = [&](int kt) {
 #pragma unroll
-            for (int it = 0; it < 2; ++it) {
+            for (int it = 0; it < AIT; ++it) {
                 const int idx = tid + it * 256;
-                const int row = idx >> 2, c = idx & 3;
-                const int64_t gm = min(m0 + row, M - 1);
-                const uint4 v = reinterpret_cast<const uint4*>(A + gm * lda + (int64_t)kt * GBK)[c];
-                *reinterpret_cast<uint4*>(&As[row * GLD + c * 8]) = v;
+                const int64_t gm = min(m0 + (idx >> 2), M - 1);
+                ra[it] = reinterpret_cast<const uint4*>(A + gm * lda + (int64_t)kt * GBK)[idx & 3];
             }
             if (W4) {
                 while (slab + 1 < plan.nslabs && kt >= plan.slab[slab + 1].slice0) ++slab;
-                if (tid < GBN) {
-                    const int64_t gn = min(n0 + tid, N - 1);
-                    const uint4* rec = reinterpret_cast<const uint4*>(Wp) + gn * plan.row16;
-                    const uint4 q = rec[plan.slab[slab].w_off16 + (kt - plan.slab[slab].slice0)];
-                    const uint32_t dw[4] = {q.x, q.y, q.z, q.w};
+                const int soff = plan.slab[slab].w_off16 + (kt - plan.slab[slab].slice0);
 #pragma unroll
-                    for (int d = 0; d < 4; ++d) {
-                        uint32_t o[4];
-#pragma unroll
-                        for (int i = 0; i < 4; ++i) o[i] = ((dw[d] >> (4 * i)) & 0x000F000Fu) | 0x43004300u;
-                        *reinterpret_cast<uint4*>(&Bs[tid * GLD + d * 8]) = make_uint4(o[0], o[1], o[2], o[3]);
-                    }
+                for (int it = 0; it < BIT; ++it) {
+                    const int idx = tid + it * 256;  // (row, dword of the slice)
+                    const int64_t gn = min(n0 + (idx >> 2), N - 1);
+                    rq[it] = reinterpret_cast<const uint32_t*>(reinterpret_cast<const uint4*>(Wp) + gn * plan.row16 + soff)[idx & 3];
                 }
             } else {
 #pragma unroll
-                for (int it = 0; it < 2; ++it) {
+                for (int it = 0; it < BIT; ++it) {
                     const int idx = tid + it * 256;
-                    const int row = idx >> 2, c = idx & 3;
-                    const int64_t gn = min(n0 + row, N - 1);
-                    const uint4 v = reinterpret_cast<const uint4*>(reinterpret_cast<const bf16_t*>(Wp) + gn * K + (int64_t)kt * GBK)[c];
-                    *reinterpret_cast<uint4*>(&Bs[row * GLD + c * 8]) = v;
+                    const int64_t gn = min(n0 + (idx >> 2), N - 1);
+                    rb[it] = reinterpret_cast<const uint4*>(reinterpret_cast<const bf16_t*>(Wp) + gn * K + (int64_t)kt * GBK)[idx & 3];
                 }
             }
-            __syncthreads();
-            // ---- 2 k-steps x (2 x 2) MFMA 32x32x16
+        };
+        // registers -> LDS stage st (int4: expand 8 nibbles to the bf16 values 128 + q)
+        auto stage = [&](int st) {
+#pragma unroll
+            for (int it = 0; it < AIT; ++it) {
+                const int idx = tid + it * 256;
+                *reinterpret_cast<uint4*>(&As[st][(idx >> 2) * GLD + (idx & 3) * 8]) = ra[it];
+            }
+#pragma unroll
+            for (int it = 0; it < BIT; ++it) {
+                const int idx = tid + it * 256;
+                uint4 v;
+                if (W4) {
+                    uint32_t o[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) o[i] = ((rq[it] >> (4 * i)) & 0x000F000Fu) | 0x43004300u;
+                    v = make_uint4(o[0], o[1], o[2], o[3]);
+                } else {
+                    v = rb[it];
+                }
+                *reinterpret_cast<uint4*>(&Bs[st][(idx >> 2) * GLD + (idx & 3) * 8]) = v;
+            }
+        };
+        fetch(0);
+        __syncthreads();  // previous pass finished with the LDS stages; xs_l is filled
+        stage(0);
+        __syncthreads();
+        for (int kt = 0; kt < ktiles; ++kt) {
+            const int st = kt & 1;
+            const int slab_now = slab;  // slab of tile kt (fetch() below may advance it)
+            if (kt + 1 < ktiles) fetch(kt + 1);
+            // ---- 2 k-steps of MFMA 32x32x16 on stage st
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
-                bf16x8_t af[2], bfr[2];
+                bf16x8_t af[IM], bfr[JN];
 #pragma unroll
-                for (int i = 0; i < 2; ++i) {
-                    const uint4 va = *reinterpret_cast<const uint4*>(&As[(wm * 64 + i * 32 + lr) * GLD + s * 16 + lh * 8]);
+                for (int i = 0; i < IM; ++i) {
+                    const uint4 va = *reinterpret_cast<const uint4*>(&As[st][(wm * (GBM / 2) + i * 32 + lr) * GLD + s * 16 + lh * 8]);
                     af[i] = __builtin_bit_cast(bf16x8_t, va);
-                    const uint4 vb = *reinterpret_cast<const uint4*>(&Bs[(wn * 64 + i * 32 + lr) * GLD + s * 16 + lh * 8]);
-                    bfr[i] = __builtin_bit_cast(bf16x8_t, vb);
                 }
 #pragma unroll
-                for (int i = 0; i < 2; ++i)
+                for (int jn = 0; jn < JN; ++jn) {
+                    const uint4 vb = *reinterpret_cast<const uint4*>(&Bs[st][(wn * (GBN / 2) + jn * 32 + lr) * GLD + s * 16 + lh * 8]);
+                    bfr[jn] = __builtin_bit_cast(bf16x8_t, vb);
+                }
 #pragma unroll
-                    for (int jn = 0; jn < 2; ++jn)
+                for (int i = 0; i < IM; ++i)
+#pragma unroll
+                    for (int jn = 0; jn < JN; ++jn)
                         acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[jn], acc[i][jn], 0, 0, 0);
             }
-            __syncthreads();
             if (W4 && ((kt + 1) % Gs == 0 || kt + 1 == ktiles)) {
                 // ---- quantisation-group boundary: fold the group's partial product into the result
                 const int g = kt / Gs;
 #pragma unroll
-                for (int jn = 0; jn < 2; ++jn) {
-                    const int64_t gn = min(n0 + wn * 64 + jn * 32 + lr, N - 1);
+                for (int jn = 0; jn < JN; ++jn) {
+                    const int64_t gn = min(n0 + wn * (GBN / 2) + jn * 32 + lr, N - 1);
                     const uint4* rec = reinterpret_cast<const uint4*>(Wp) + gn * plan.row16;
-                    const uint32_t mt = reinterpret_cast<const uint32_t*>(rec + plan.slab[slab].meta_off16)[g - plan.slab[slab].g0];
+                    const uint32_t mt = reinterpret_cast<const uint32_t*>(rec + plan.slab[slab_now].meta_off16)[g - plan.slab[slab_now].g0];
                     const float sc = bflo(mt), zz = 128.0f + bfhi(mt);
 #pragma unroll
-                    for (int i = 0; i < 2; ++i)
+                    for (int i = 0; i < IM; ++i)
 #pragma unroll
                         for (int r = 0; r < 16; ++r) {
-                            const int64_t gm = min(m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh, M - 1);
-                            total[i][jn][r] += sc * (acc[i][jn][r] - zz * xsum[gm * ngroups + g]);
+                            const int lm = wm * (GBM / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                            const float xs = xs_lds ? xs_l[lm * ngroups + g] : xsum[(int64_t)min(m0 + lm, M - 1) * ngroups + g];
+                            total[i][jn][r] += sc * (acc[i][jn][r] - zz * xs);
                             acc[i][jn][r] = 0.f;
                         }
                 }
             }
+            if (kt + 1 < ktiles) stage(st ^ 1);  // stage st^1 was last read in iteration kt-1, before the barrier below it
+            __syncthreads();
         }
         if (!W4) {
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+            for (int i = 0; i < IM; ++i)
 #pragma unroll
-                for (int jn = 0; jn < 2; ++jn) total[i][jn] = acc[i][jn];
+                for (int jn = 0; jn < JN; ++jn) total[i][jn] = acc[i][jn];
         }
         if (npass == 2 && pass == 0) {
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+            for (int i = 0; i < IM; ++i)
 #pragma unroll
-                for (int jn = 0; jn < 2; ++jn)
+                for (int jn = 0; jn < JN; ++jn)
 #pragma unroll
                     for (int r = 0; r < 16; r += 2) {
                         const bf16_t g0 = f2bf(silu(rbf(total[i][jn][r]))), g1 = f2bf(silu(rbf(total[i][jn][r + 1])));
@@ -167,13 +208,13 @@ gemm_kernel(const bf16_t* __restrict__ A, int lda, int M, const void* __restrict
     }
     // ---- epilogue: C layout of the 32x32 MFMA: column = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < IM; ++i)
 #pragma unroll
-        for (int jn = 0; jn < 2; ++jn) {
-            const int col = n0 + wn * 64 + jn * 32 + lr;
+        for (int jn = 0; jn < JN; ++jn) {
+            const int col = n0 + wn * (GBN / 2) + jn * 32 + lr;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                const int row = m0 + wm * (GBM / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
                 if (row < M && col < N) {
                     bf16_t o;
                     if (epi == PARROT_EPI_SWIGLU) {
@@ -188,6 +229,9 @@ gemm_kernel(const bf16_t* __restrict__ A, int lda, int M, const void* __restrict
             }
         }
 }
+
+// 128 x 128 tiles only when they alone give the chip >= 2 workgroups per CU; otherwise 64 x 64 (4x the workgroups)
+static bool gemm_big_tiles(int M, int N) { return (int64_t)((M + 127) / 128) * ((N + 127) / 128) >= 512; }
 
 }  // namespace parrot
 
@@ -208,11 +252,16 @@ int parrot_bf16_gemm(const void* W, const void* W2, const void* x, int ldx, int 
     PARROT_UNSUPPORTED(norm == nullptr || norm->kind == 0, "bf16_gemm: apply the norm to the rows first (parrot_rmsnorm / parrot_layernorm)");
     PARROT_UNSUPPORTED(K % GBK == 0, "bf16_gemm: K=%d must be a multiple of %d", K, GBK);
     PARROT_UNSUPPORTED(!(epilogue == PARROT_EPI_SWIGLU && bias), "bf16_gemm: SWIGLU epilogue takes no bias");
-    PARROT_REQUIRE(M <= 65535 * GBM, "bf16_gemm: M too large");
+    PARROT_REQUIRE(M <= 65535 * 64, "bf16_gemm: M too large");
     W4Plan plan = {};
-    const dim3 grid((N + GBN - 1) / GBN, (M + GBM - 1) / GBM);
-    return launch(K_BF16_GEMM, gemm_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, ldx, M, W, W2, N, K,
-                  (const float*)nullptr, (const bf16_t*)bias, (const bf16_t*)residual, ldr, (bf16_t*)out, ldo, epilogue, plan);
+    if (gemm_big_tiles(M, N)) {
+        const dim3 grid((N + 127) / 128, (M + 127) / 128);
+        return launch(K_BF16_GEMM, gemm_kernel<false, 128, 128>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, ldx, M, W, W2,
+                      N, K, (const float*)nullptr, (const bf16_t*)bias, (const bf16_t*)residual, ldr, (bf16_t*)out, ldo, epilogue, 0, plan);
+    }
+    const dim3 grid((N + 63) / 64, (M + 63) / 64);
+    return launch(K_BF16_GEMM, gemm_kernel<false, 64, 64>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, ldx, M, W, W2, N, K,
+                  (const float*)nullptr, (const bf16_t*)bias, (const bf16_t*)residual, ldr, (bf16_t*)out, ldo, epilogue, 0, plan);
 }
 
 int parrot_w4_gemm(const void* packed, const void* packed2, const void* x, int ldx, int M, const void* bias,
@@ -234,9 +283,21 @@ int parrot_w4_gemm(const void* packed, const void* packed2, const void* x, int l
     rc = launch(K_W4_GEMM, gemm_xsum_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (const bf16_t*)x, ldx, M, K, G,
                 plan.ngroups, (float*)workspace);
     if (rc != PARROT_OK) return rc;
-    const dim3 grid((N + GBN - 1) / GBN, (M + GBM - 1) / GBM);
-    return launch(K_W4_GEMM, gemm_kernel<true>, grid, dim3(256), 0, st, (const bf16_t*)x, ldx, M, packed, packed2, N, K,
-                  (const float*)workspace, (const bf16_t*)bias, (const bf16_t*)residual, ldr, (bf16_t*)out, ldo, epilogue, plan);
+    // the tile's activation sums live in LDS when they fit next to the two stages (64 KB without opting in to more)
+    if (gemm_big_tiles(M, N)) {
+        const size_t xb = (size_t)128 * plan.ngroups * 4;
+        const int in_lds = xb <= 20 * 1024;
+        const dim3 grid((N + 127) / 128, (M + 127) / 128);
+        return launch(K_W4_GEMM, gemm_kernel<true, 128, 128>, grid, dim3(256), in_lds ? xb : 0, st, (const bf16_t*)x, ldx, M, packed,
+                      packed2, N, K, (const float*)workspace, (const bf16_t*)bias, (const bf16_t*)residual, ldr, (bf16_t*)out, ldo,
+                      epilogue, in_lds, plan);
+    }
+    const size_t xb = (size_t)64 * plan.ngroups * 4;
+    const int in_lds = xb <= 40 * 1024;
+    const dim3 grid((N + 63) / 64, (M + 63) / 64);
+    return launch(K_W4_GEMM, gemm_kernel<true, 64, 64>, grid, dim3(256), in_lds ? xb : 0, st, (const bf16_t*)x, ldx, M, packed, packed2,
+                  N, K, (const float*)workspace, (const bf16_t*)bias, (const bf16_t*)residual, ldr, (bf16_t*)out, ldo, epilogue,
+                  in_lds, plan);
 }
 
 }  // extern "C"

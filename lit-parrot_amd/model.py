@@ -23,6 +23,7 @@ Deliberate differences from the reference (documented in DESIGN.md): the KV cach
 window of keys, in a different slot order; ``input_pos`` must be consecutive positions.
 """
 import math
+import os
 from typing import Any, List, Optional, Tuple
 
 import torch
@@ -32,6 +33,9 @@ from . import ops
 from ._hip import EPI_GELU, EPI_NONE, EPI_RESIDUAL, EPI_SWIGLU, ParrotHipError
 from .config import Config
 from .rmsnorm import RMSNorm
+
+# parallel-residual blocks: overlap the MLP up-projection with the attention branch (M = 1); PARROT_PARALLEL_BRANCHES=0 disables
+PARALLEL_BRANCHES = os.environ.get("PARROT_PARALLEL_BRANCHES", "1") != "0"
 
 RoPECache = Tuple[torch.Tensor, torch.Tensor]
 KVCache = Tuple[torch.Tensor, torch.Tensor]
@@ -57,6 +61,7 @@ class Workspace:
         self.h = buf(c.intermediate_size)
         self.logits = buf(c.padded_vocab_size, lm_rows)
         self.zero_pos = torch.zeros((1,), dtype=torch.int32, device=device)
+        self.side_stream = None  # parallel-residual blocks: the MLP's first Linear runs beside the attention branch
         self.tickets = torch.zeros((c.n_head,), dtype=torch.int32, device=device)  # fused attention arrival counters
         self._attn_ws = {}
 
@@ -243,17 +248,34 @@ class Block(nn.Module):
         """One block over ``ws.x`` in place (reference Block.forward, model.py:158-180)."""
         c = self.config
         # norm_1 is fused into the QKV linear, norm_2 into the MLP's first linear: no normalised copy is materialised
-        self.attn.run_rows(ws, ws.x, pos, S, k_cache, v_cache, rope, nsplit, rope_local, norm=self.norm_1)  # -> ws.y
         if c.parallel_residual:
-            # x + h + mlp(n_2): the first sum is rounded to bf16 before the second, as in the reference (:171)
+            # x + h + mlp(n_2): the first sum is rounded to bf16 before the second, as in the reference (:171).
+            # The two branches only meet at that sum, so for a single token the MLP's up-projection is enqueued on a side
+            # stream next to [QKV -> attention -> proj]: inside the captured graph they become parallel nodes and the
+            # weight stream of one covers the dispatch / latency gaps of the other.
+            mlp_norm = self.norm_1 if c.shared_attention_norm else self.norm_2
+            if PARALLEL_BRANCHES and ws.M == 1:
+                if ws.side_stream is None:
+                    ws.side_stream = torch.cuda.Stream(device=ws.x.device)
+                main = torch.cuda.current_stream(ws.x.device)
+                ws.side_stream.wait_stream(main)  # x of this block is final
+                with torch.cuda.stream(ws.side_stream):
+                    self.mlp.run_up(ws, ws.x, norm=mlp_norm)  # -> ws.h
+                self.attn.run_rows(ws, ws.x, pos, S, k_cache, v_cache, rope, nsplit, rope_local, norm=self.norm_1)
+                _linear(self.attn.proj, ws.y, ws.t, epilogue=EPI_RESIDUAL, residual=ws.x)
+                main.wait_stream(ws.side_stream)
+                self.mlp.run_down(ws, residual=ws.t, out=ws.x)
+                return
+            self.attn.run_rows(ws, ws.x, pos, S, k_cache, v_cache, rope, nsplit, rope_local, norm=self.norm_1)  # -> ws.y
             _linear(self.attn.proj, ws.y, ws.t, epilogue=EPI_RESIDUAL, residual=ws.x)
-            self.mlp.run_rows(ws, ws.x, residual=ws.t, out=ws.x, norm=self.norm_1 if c.shared_attention_norm else self.norm_2)
+            self.mlp.run_rows(ws, ws.x, residual=ws.t, out=ws.x, norm=mlp_norm)
         else:
             if c.shared_attention_norm:
                 raise NotImplementedError(
                     "No checkpoint amongst the ones we support uses this configuration"
                     " (non-parallel residual and shared attention norm)."
                 )
+            self.attn.run_rows(ws, ws.x, pos, S, k_cache, v_cache, rope, nsplit, rope_local, norm=self.norm_1)  # -> ws.y
             _linear(self.attn.proj, ws.y, ws.x, epilogue=EPI_RESIDUAL, residual=ws.x)  # x = x + h
             self.mlp.run_rows(ws, ws.x, residual=ws.x, out=ws.x, norm=self.norm_2)  # x = x + mlp(norm_2(x))
 
@@ -336,7 +358,13 @@ class GptNeoxMLP(nn.Module):
 
     def run_rows(self, ws: Workspace, x: torch.Tensor, *, residual: Optional[torch.Tensor], out: torch.Tensor,
                  norm: Optional[nn.Module] = None) -> torch.Tensor:
-        _linear(self.fc, x, ws.h, epilogue=EPI_GELU, norm=norm)  # exact-erf GELU fused (model.py:284-287)
+        self.run_up(ws, x, norm=norm)
+        return self.run_down(ws, residual=residual, out=out)
+
+    def run_up(self, ws, x: torch.Tensor, *, norm: Optional[nn.Module] = None) -> torch.Tensor:
+        return _linear(self.fc, x, ws.h, epilogue=EPI_GELU, norm=norm)  # exact-erf GELU fused (model.py:284-287)
+
+    def run_down(self, ws, *, residual: Optional[torch.Tensor], out: torch.Tensor) -> torch.Tensor:
         return _linear(self.proj, ws.h, out, epilogue=EPI_RESIDUAL if residual is not None else EPI_NONE, residual=residual)
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
@@ -354,7 +382,13 @@ class LLaMAMLP(nn.Module):
 
     def run_rows(self, ws: Workspace, x: torch.Tensor, *, residual: Optional[torch.Tensor], out: torch.Tensor,
                  norm: Optional[nn.Module] = None) -> torch.Tensor:
-        _linear(self.fc_1, x, ws.h, epilogue=EPI_SWIGLU, partner=self.fc_2, norm=norm)  # silu(fc_1 x) * fc_2 x (model.py:297-301)
+        self.run_up(ws, x, norm=norm)
+        return self.run_down(ws, residual=residual, out=out)
+
+    def run_up(self, ws, x: torch.Tensor, *, norm: Optional[nn.Module] = None) -> torch.Tensor:
+        return _linear(self.fc_1, x, ws.h, epilogue=EPI_SWIGLU, partner=self.fc_2, norm=norm)  # silu(fc_1 x) * fc_2 x (model.py:297-301)
+
+    def run_down(self, ws, *, residual: Optional[torch.Tensor], out: torch.Tensor) -> torch.Tensor:
         return _linear(self.proj, ws.h, out, epilogue=EPI_RESIDUAL if residual is not None else EPI_NONE, residual=residual)
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
