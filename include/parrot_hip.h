@@ -154,6 +154,9 @@ int parrot_attn_fused_decode(const void* qkv, const void* rope_cos, const void* 
  * x[m] = wte[tokens[(pos ? *pos : 0) + m]]   (lit_gpt/model.py:99)                    */
 int parrot_embedding(const void* wte, int d, const int64_t* tokens, const int32_t* pos, int M,
                      void* out, int ldo, void* stream);
+/* Pull a read-only buffer (weights of the NEXT Linear) on chip from a side stream while the current kernel runs; no
+ * dependency on it is ever needed. */
+int parrot_prefetch(const void* data, int64_t bytes, int workgroups, void* stream);
 /* greedy step of generate() (generate/base.py:136-153 with top_k=1):
  * tokens[*pos + 1] = argmax(logits) (lowest index on ties); then *pos += 1.          */
 int parrot_argmax_advance(const void* logits, int V, int64_t* tokens, int32_t* pos, void* stream);

@@ -87,6 +87,7 @@ SIGNATURES = {
     "parrot_pk_fill_w4": (_i, [C.POINTER(PkOp), _i, _i, _i]),
     "parrot_pk_step": (_i, [C.POINTER(PkState), _vp]),
     "parrot_embedding": (_i, [_vp, _i, _vp, _vp, _i, _vp, _i, _vp]),
+    "parrot_prefetch": (_i, [_vp, _i64, _i, _vp]),
     "parrot_argmax_advance": (_i, [_vp, _i, _vp, _vp, _vp]),
 }
 

@@ -66,6 +66,7 @@ enum KernelId : int {
     K_BF16_GEMM,
     K_ATTN_FUSED,
     K_PK_TOKEN,
+    K_PREFETCH,
     K_COUNT
 };
 

@@ -37,6 +37,10 @@ from .rmsnorm import RMSNorm
 # parallel-residual blocks: overlap the MLP up-projection with the attention branch (M = 1); PARROT_PARALLEL_BRANCHES=0 disables
 PARALLEL_BRANCHES = os.environ.get("PARROT_PARALLEL_BRANCHES", "1") != "0"
 
+# decode step of sequential-residual models: pull the NEXT Linear's weights on chip from a side stream while the current
+# kernel runs (PARROT_PREFETCH=0 disables; =N limits each prefetch to N MiB)
+WEIGHT_PREFETCH = os.environ.get("PARROT_PREFETCH", "0")
+
 RoPECache = Tuple[torch.Tensor, torch.Tensor]
 KVCache = Tuple[torch.Tensor, torch.Tensor]
 
@@ -71,6 +75,52 @@ class Workspace:
         return self._attn_ws[nsplit]
 
 
+class WeightPrefetcher:
+    """Side-stream prefetch of the weights of the Linear that runs AFTER the one being launched.
+
+    The decode step is a dependency chain of weight-streaming kernels; between two of them the HBM idles for the
+    dispatch, arithmetic and tail phases (~4-5 us).  Each Linear launch is therefore preceded by a tiny read-only
+    kernel on a side stream (gated on the previous kernel's completion) that touches the next Linear's weights, so that
+    they come from the Infinity Cache when their kernel starts.  Nothing depends on the prefetch: it cannot change results.
+    """
+
+    def __init__(self, model: "GPT", device, limit_bytes: Optional[int]) -> None:
+        self.side = torch.cuda.Stream(device=device)
+        self.limit = limit_bytes
+        launches = []
+        for block in model.transformer.h:
+            launches.append([block.attn.attn])
+            launches.append([block.attn.proj])
+            mlp = block.mlp
+            launches.append([mlp.fc_1, mlp.fc_2] if hasattr(mlp, "fc_1") else [mlp.fc])
+            launches.append([mlp.proj])
+        launches.append([model.lm_head])
+        self.index = {id(group[0]): i for i, group in enumerate(launches)}
+        self.tensors = [[self._weight(m) for m in group] for group in launches]
+
+    @staticmethod
+    def _weight(mod: nn.Module) -> torch.Tensor:
+        if hasattr(mod, "packed"):
+            return mod.packed()
+        return mod.weight.data
+
+    def before(self, mod: nn.Module) -> None:
+        i = self.index.get(id(mod))
+        if i is None:
+            return
+        main = torch.cuda.current_stream(self.side.device)
+        self.side.wait_stream(main)  # the kernel before `mod` has finished: the prefetch runs beside `mod`'s kernel
+        with torch.cuda.stream(self.side):
+            for t in self.tensors[(i + 1) % len(self.tensors)]:
+                ops.prefetch(t, 256, self.limit)
+
+    def join(self) -> None:
+        torch.cuda.current_stream(self.side.device).wait_stream(self.side)
+
+
+_ACTIVE_PREFETCHER: Optional[WeightPrefetcher] = None
+
+
 def _fused_norm(mod: Optional[nn.Module]) -> Optional[ops.Norm]:
     """Describe a norm module so that the following Linear applies it to its input rows on the fly."""
     if mod is None:
@@ -87,6 +137,8 @@ def _linear(mod: nn.Module, x: torch.Tensor, out: torch.Tensor, *, epilogue: int
     """Run one Linear-shaped module on rows with a fused epilogue — and optionally the norm module in front of it
     fused as a prologue — whatever class ``quantization()`` installed."""
     norm = _fused_norm(norm)
+    if _ACTIVE_PREFETCHER is not None and x.shape[0] == 1:
+        _ACTIVE_PREFETCHER.before(mod)
     if hasattr(mod, "hip_linear"):
         return mod.hip_linear(x, out, epilogue=epilogue, residual=residual, partner=partner, norm=norm)
     if isinstance(mod, nn.Linear):
@@ -184,13 +236,25 @@ class GPT(nn.Module):
         ``pos`` (device int32[1]) is the position of row 0; ``caches[i]`` are (n_groups, S, hs) views.  Returns
         ``ws.logits``: all rows, or only the last row when the workspace was built with ``lm_rows == 1``.
         """
+        global _ACTIVE_PREFETCHER
         M = ws.M
         ops.embedding(self.transformer.wte.weight.data, tokens, tok_pos, M, ws.x)
         nsplit = ops.attn_nsplit(self.config.n_query_groups, S, self.config.q_per_kv)
-        for block, (kc, vc) in zip(self.transformer.h, caches):
-            block.run_rows(ws, pos, S, kc, vc, rope, nsplit, rope_local)
-        last = ws.x if ws.lm_rows == M else ws.x[M - 1:M]
-        return _linear(self.lm_head, last, ws.logits, norm=self.transformer.ln_f)  # ln_f fused into lm_head
+        use_pf = M == 1 and WEIGHT_PREFETCH != "0" and not self.config.parallel_residual
+        if use_pf and getattr(self, "_prefetcher", None) is None:
+            lim = int(WEIGHT_PREFETCH) * (1 << 20) if WEIGHT_PREFETCH.isdigit() and int(WEIGHT_PREFETCH) > 1 else None
+            self._prefetcher = WeightPrefetcher(self, ws.x.device, lim)
+        _ACTIVE_PREFETCHER = self._prefetcher if use_pf else None
+        try:
+            for block, (kc, vc) in zip(self.transformer.h, caches):
+                block.run_rows(ws, pos, S, kc, vc, rope, nsplit, rope_local)
+            last = ws.x if ws.lm_rows == M else ws.x[M - 1:M]
+            logits = _linear(self.lm_head, last, ws.logits, norm=self.transformer.ln_f)  # ln_f fused into lm_head
+            if _ACTIVE_PREFETCHER is not None:
+                _ACTIVE_PREFETCHER.join()
+        finally:
+            _ACTIVE_PREFETCHER = None
+        return logits
 
     def forward(self, idx: torch.Tensor, max_seq_length: Optional[int] = None,
                 input_pos: Optional[torch.Tensor] = None) -> torch.Tensor:

@@ -246,3 +246,9 @@ def argmax_advance(logits: torch.Tensor, tokens: torch.Tensor, pos: torch.Tensor
         raise ParrotHipError("argmax_advance: logits bf16, tokens int64, pos int32 expected")
     check(_hip.load().parrot_argmax_advance(ptr(logits), logits.numel(), ptr(tokens), ptr(pos), stream()),
           "parrot_argmax_advance")
+
+
+def prefetch(t: torch.Tensor, workgroups: int = 256, nbytes: Optional[int] = None) -> None:
+    """Enqueue (on the current stream) a read of ``t`` that leaves its lines in the on-chip caches."""
+    n = t.numel() * t.element_size() if nbytes is None else min(nbytes, t.numel() * t.element_size())
+    check(_hip.load().parrot_prefetch(ptr(t), n, workgroups, stream()), "parrot_prefetch")

@@ -249,3 +249,71 @@ def test_block_and_attention_standalone_calls():
         want_a, _ = oracle.attention(0, x, cos[:5], sin[:5], 5, None, None, None)
         got_a, _ = model.transformer.h[0].attn(x.to(DEV), (cos[:5].to(DEV), sin[:5].to(DEV)), 5)
         assert float((got_a.cpu().float() - want_a.float()).abs().max()) <= 2 ** -6
+
+
+# ------------------------------------------------------------------------------------------------ edge cases
+def test_edge_cases_of_the_loop_and_forward():
+    """Ragged / minimal inputs the reference accepts: one-token prompts, a window exactly as long as the prompt, batch > 1,
+    eos on the very first generated token, sampling without top-k, and the reference's argument checks."""
+    cfg = Config.from_name("tiny-llama")
+    sd = {k: v.to(BF) for k, v in synthetic_state_dict(cfg, MODEL_SEED, perturb=True).items()}
+    model = hip_model(cfg, sd)
+    oracle = om.OracleGPT(cfg, sd)
+    # one-token prompt
+    p1 = synthetic_prompt(cfg, 1, 11)
+    y = L.generate(model, p1.to(DEV), 9, 9, top_k=1).cpu()
+    assert y.shape == (9,) and int(y[0]) == int(p1[0])
+    assert greedy_agreement(y, oracle, 1, 9) >= 0.75
+    # eos on the first generated token: the reference returns the prompt only (slice stops before eos)
+    model.reset_cache()
+    y_eos = L.generate(model, p1.to(DEV), 9, 9, top_k=1, eos_id=int(y[1])).cpu()
+    assert torch.equal(y_eos, y[:1])
+    # max_seq_length == prompt length + 1 (the smallest window generate() accepts for one new token)
+    model.reset_cache()
+    p5 = synthetic_prompt(cfg, 5, 12)
+    y5 = L.generate(model, p5.to(DEV), 6, 6, top_k=1).cpu()
+    assert y5.shape == (6,) and torch.equal(y5[:5], p5)
+    # sampling without top-k (temperature only) runs the reference's torch ops
+    model.reset_cache()
+    torch.manual_seed(1)
+    ys = L.generate(model, p5.to(DEV), 12, 12, temperature=0.7, top_k=None).cpu()
+    assert ys.shape == (12,) and int(ys.max()) < cfg.padded_vocab_size
+    # batch of 2 sequences through forward (no cache and with cache)
+    model.reset_cache()
+    idx = torch.stack([synthetic_prompt(cfg, 6, 13), synthetic_prompt(cfg, 6, 14)])
+    with torch.no_grad():
+        out = model(idx.to(DEV)).float().cpu()
+        ref = oracle(idx).float()
+        assert out.shape == (2, 6, cfg.padded_vocab_size)
+        assert float((out - ref).abs().max()) <= 2 ** -5
+        oracle.reset_cache()
+        pos = torch.arange(6)
+        out_c = model(idx.to(DEV), 8, pos.to(DEV)).float().cpu()
+        ref_c = oracle(idx, 8, pos).float()
+        assert float((out_c - ref_c).abs().max()) <= 2 ** -5
+        assert model.kv_caches[0][0].shape[0] == 2
+    # the reference's argument checks (model.py:73-77, generate/base.py:115)
+    model.reset_cache()
+    with pytest.raises(AssertionError):
+        model(idx[:1].to(DEV), cfg.block_size + 1)
+    with pytest.raises(AssertionError):
+        model(idx[:1].to(DEV), 4, torch.arange(6, device=DEV))  # max_seq_length < T with a cache
+    with pytest.raises(AssertionError):
+        L.generate(model, p5.to(DEV), 5, 5)  # max_returned_tokens must exceed the prompt
+
+
+def test_unsupported_shapes_fail_loudly():
+    """Falcon-7B-like shapes (n_embd not a multiple of 128, 71 query heads per group) are outside the int4 g128 and fused
+    attention kernels: the int4 path refuses with a message, it never falls back to torch."""
+    from lit_parrot_amd import ops as O
+
+    with pytest.raises(L.ParrotHipError, match="multiple of 32"):
+        O.w4_packed_bytes(64, 4544 // 2 + 4, 128)  # K = 2276
+    lin = torch.nn.Linear(64, 64).to(BF).to(DEV)
+    x = torch.randn(1, 64, device=DEV)  # fp32 activations
+    with pytest.raises(L.ParrotHipError, match="bf16"):
+        O.bf16_linear(lin.weight.data, x, torch.empty(1, 64, dtype=BF, device=DEV))
+    with pytest.raises(L.ParrotHipError):
+        O.attn_decode(torch.empty(1, 48, dtype=BF, device=DEV), torch.zeros(1, dtype=torch.int32, device=DEV),
+                      torch.empty(1, 8, 48, dtype=BF, device=DEV), torch.empty(1, 8, 48, dtype=BF, device=DEV), 1, 1, 48, 8, 1,
+                      None, torch.empty(1, 48, dtype=BF, device=DEV))  # head size 48 is not built
