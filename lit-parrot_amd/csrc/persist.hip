@@ -36,12 +36,7 @@ typedef parrot_pk_op_t PkOp;
 typedef parrot_pk_state_t PkState;
 
 // ---- agent-scope (write-through / L1-bypassing) accessors for data that other workgroups produce or consume
-__device__ __forceinline__ uint64_t ld_agent64(const void* p) {
-    return __hip_atomic_load(reinterpret_cast<const uint64_t*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ uint32_t ld_agent32(const void* p) {
-    return __hip_atomic_load(reinterpret_cast<const uint32_t*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
+// (ld_agent64 / ld_agent32 live in parrot_common.h)
 __device__ __forceinline__ float ld_agentf(const float* p) {
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
