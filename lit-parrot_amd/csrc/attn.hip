@@ -229,17 +229,18 @@ __device__ __forceinline__ float load_agent(const float* p) {
 // CHAIN = true: chained-launch form (parrot_common.h).  The RoPE table entries and the first K/V rows are requested,
 // then the workgroup waits for the QKV launch in-kernel and reads its group's rows with agent-scope loads; y is written
 // with write-through stores and every workgroup signals once its part (partials, or the merged heads) has drained.
-template <int HS, int HQ, bool CHAIN>
-__global__ void __launch_bounds__(kAttnWaves * 64)
+// WAVES = 4 or 16 wavefronts per workgroup: with 16, one workgroup walks 64 (hs 128) .. 256 (hs 32) keys per step, so
+// that contexts up to ~1k keys need no cross-workgroup split at all (no partials, no ticket, no second pass).
+template <int HS, int HQ, int WAVES, bool CHAIN>
+__global__ void __launch_bounds__(WAVES * 64)
 attn_fused_decode_kernel(const bf16_t* qkv, const __half* __restrict__ rope_cos,
                          const __half* __restrict__ rope_sin, int n_elem, const int32_t* __restrict__ pos_ptr,
                          bf16_t* __restrict__ k_cache, bf16_t* __restrict__ v_cache, int n_groups, int q_per_kv, int S,
                          int nsplit, float* __restrict__ ws, unsigned int* __restrict__ tickets, bf16_t* y, ChainArgs ca) {
     constexpr int LPR = HS / 8;
     constexpr int RPW = 64 / LPR;
-    constexpr int NSLOT = kAttnWaves * RPW;
-    __shared__ float sh_acc[HQ][NSLOT][HS];
-    __shared__ float sh_m[HQ][NSLOT], sh_l[HQ][NSLOT];
+    __shared__ float sh_acc[HQ][WAVES][HS];  // one merged state per wave
+    __shared__ float sh_m[HQ][WAVES], sh_l[HQ][WAVES];
     __shared__ float sh_q[kFusedMaxQ][HS];  // roped, bf16-rounded, pre-scaled by 1/sqrt(hs)
     __shared__ __attribute__((aligned(16))) bf16_t sh_kv[2][HS];  // roped k_new, v_new as stored in the cache
     __shared__ int sh_last;
@@ -259,18 +260,17 @@ attn_fused_decode_kernel(const bf16_t* qkv, const __half* __restrict__ rope_cos,
 
     const uint4* kc = reinterpret_cast<const uint4*>(k_cache + (int64_t)g * S * HS);
     const uint4* vc = reinterpret_cast<const uint4*>(v_cache + (int64_t)g * S * HS);
-    const int slot = wave * RPW + sub;
-    constexpr int STRIDE = kAttnWaves * RPW;
+    constexpr int STRIDE = WAVES * RPW;
     // Load order matters (vmcnt retires in order): first the small L2-resident operands of the RoPE phase (this
     // group's q/k/v rows, cos/sin), then the first K/V rows of this wave, which do not depend on q — their HBM latency
     // overlaps the split + RoPE phase.  (Rows past the range are clamped; the appended row is replaced later.)
-    constexpr int ROPE_IT = ((kFusedMaxQ + 2) * HS + kAttnWaves * 64 - 1) / (kAttnWaves * 64);
+    constexpr int ROPE_IT = ((kFusedMaxQ + 2) * HS + WAVES * 64 - 1) / (WAVES * 64);
     const bf16_t* grp = qkv + (int64_t)g * (q_per_kv + 2) * HS;
     const int n_rope_elems = (q_per_kv + 2) * HS;
     float rx[ROPE_IT], ro[ROPE_IT], rc[ROPE_IT], rs[ROPE_IT];
 #pragma unroll
     for (int it = 0; it < ROPE_IT; ++it) {
-        const int idx = threadIdx.x + it * kAttnWaves * 64;
+        const int idx = threadIdx.x + it * WAVES * 64;
         rx[it] = ro[it] = rs[it] = 0.f;
         rc[it] = 1.f;
         if (idx < n_rope_elems) {
@@ -296,7 +296,7 @@ attn_fused_decode_kernel(const bf16_t* qkv, const __half* __restrict__ rope_cos,
         chain_stamp(ca, 1);
 #pragma unroll
         for (int it = 0; it < ROPE_IT; ++it) {
-            const int idx = threadIdx.x + it * kAttnWaves * 64;
+            const int idx = threadIdx.x + it * WAVES * 64;
             if (idx < n_rope_elems) {
                 const int t = idx / HS, d = idx % HS;
                 rx[it] = bf2f(ld_agent16(grp + idx));
@@ -310,7 +310,7 @@ attn_fused_decode_kernel(const bf16_t* qkv, const __half* __restrict__ rope_cos,
     // the sum rounded to fp32 separately; elements outside the rotary part pass through (cos = 1, sin = 0 is exact)
 #pragma unroll
     for (int it = 0; it < ROPE_IT; ++it) {
-        const int idx = threadIdx.x + it * kAttnWaves * 64;
+        const int idx = threadIdx.x + it * WAVES * 64;
         if (idx < n_rope_elems) {
             const int t = idx / HS, d = idx % HS;
             const float v = __fadd_rn(__fmul_rn(rx[it], rc[it]), __fmul_rn(ro[it], rs[it]));
@@ -390,20 +390,34 @@ attn_fused_decode_kernel(const bf16_t* qkv, const __half* __restrict__ rope_cos,
             kv_cur = kv_nxt;
             vv_cur = vv_nxt;
         }
-        __syncthreads();
+        // merge the RPW row slots of this wave with xor shuffles (fixed order), then one state per wave goes to LDS
 #pragma unroll
         for (int hh = 0; hh < HQ; ++hh) {
 #pragma unroll
-            for (int e = 0; e < 8; ++e) sh_acc[hh][slot][dl * 8 + e] = acc[hh][e];
-            if (dl == 0) {
-                sh_m[hh][slot] = mrun[hh];
-                sh_l[hh][slot] = lrun[hh];
+            for (int off = LPR; off < 64; off <<= 1) {
+                const float m_o = __shfl_xor(mrun[hh], off, 64), l_o = __shfl_xor(lrun[hh], off, 64);
+                const float mn = fmaxf(mrun[hh], m_o);
+                const float c1 = (mrun[hh] == -INFINITY) ? 0.f : __expf(mrun[hh] - mn);
+                const float c2 = (m_o == -INFINITY) ? 0.f : __expf(m_o - mn);
+                lrun[hh] = lrun[hh] * c1 + l_o * c2;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) acc[hh][e] = acc[hh][e] * c1 + __shfl_xor(acc[hh][e], off, 64) * c2;
+                mrun[hh] = mn;
+            }
+            if (sub == 0) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) sh_acc[hh][wave][dl * 8 + e] = acc[hh][e];
+                if (dl == 0) {
+                    sh_m[hh][wave] = mrun[hh];
+                    sh_l[hh][wave] = lrun[hh];
+                }
             }
         }
         __syncthreads();
-        for (int idx = threadIdx.x; idx < HQ * HS; idx += kAttnWaves * 64) {
+        for (int idx = threadIdx.x; idx < HQ * HS; idx += WAVES * 64) {
             const int hh = idx / HS, d = idx % HS;
             if (h0 + hh < q_per_kv) {
+                constexpr int NSLOT = WAVES;
                 float mx = -INFINITY;
                 for (int t = 0; t < NSLOT; ++t) mx = fmaxf(mx, sh_m[hh][t]);
                 float l = 0.f, a = 0.f;
@@ -453,7 +467,7 @@ attn_fused_decode_kernel(const bf16_t* qkv, const __half* __restrict__ rope_cos,
         if (CHAIN && threadIdx.x == 0) chain_signal(ca, wg_linear);  // its partials are already visible
         return;
     }
-    for (int idx = threadIdx.x; idx < HQ * HS; idx += kAttnWaves * 64) {
+    for (int idx = threadIdx.x; idx < HQ * HS; idx += WAVES * 64) {
         const int hq = h0 + idx / HS, d = idx % HS;
         if (hq >= q_per_kv) continue;
         const int head = g * q_per_kv + hq;
@@ -484,7 +498,10 @@ static int attn_fused_launch(const void* qkv, const void* cosp, const void* sinp
                              void* k_cache, void* v_cache, int n_groups, int q_per_kv, int S, int nsplit, void* ws,
                              void* tickets, void* y, parrot_chain_t* ch, hipStream_t st) {
     const int hq = q_per_kv == 1 ? 1 : (q_per_kv == 2 ? 2 : 4);
-    const dim3 grid(n_groups, nsplit, (q_per_kv + hq - 1) / hq), block(kAttnWaves * 64);
+    // 16 waves when a split holds more keys than 4 waves cover in two steps; chained launches keep the 4-wave shape
+    const int per = (S + nsplit - 1) / nsplit;
+    const bool wide = !CHAIN && per > 2 * kAttnWaves * (64 / (HS / 8));
+    const dim3 grid(n_groups, nsplit, (q_per_kv + hq - 1) / hq), block((wide ? 16 : kAttnWaves) * 64);
     ChainArgs ca{nullptr, 0u, nullptr, nullptr, nullptr};
     if (CHAIN) {
         // co-residency rule of chained launches: <= 256 workgroups (4 waves x <= 136 VGPRs, <= 42 KB LDS each)
@@ -493,13 +510,20 @@ static int attn_fused_launch(const void* qkv, const void* cosp, const void* sinp
         ca = ChainArgs{ch->wait, ch->wait_target, ch->signal, ch->err, (unsigned long long*)ch->stamps};
         ch->workgroups = (uint32_t)wgs;
     }
-#define PARROT_FUSED_GO(HQV)                                                                                          \
-    return launch(K_ATTN_FUSED, attn_fused_decode_kernel<HS, HQV, CHAIN>, grid, block, 0, st, (const bf16_t*)qkv,     \
-                  (const __half*)cosp, (const __half*)sinp, n_elem, pos, (bf16_t*)k_cache, (bf16_t*)v_cache, n_groups, \
+#define PARROT_FUSED_GO(HQV, WV)                                                                                        \
+    return launch(K_ATTN_FUSED, attn_fused_decode_kernel<HS, HQV, WV, CHAIN>, grid, block, 0, st, (const bf16_t*)qkv,   \
+                  (const __half*)cosp, (const __half*)sinp, n_elem, pos, (bf16_t*)k_cache, (bf16_t*)v_cache, n_groups,   \
                   q_per_kv, S, nsplit, (float*)ws, (unsigned int*)tickets, (bf16_t*)y, ca)
-    if (q_per_kv == 1) PARROT_FUSED_GO(1);
-    if (q_per_kv == 2) PARROT_FUSED_GO(2);
-    PARROT_FUSED_GO(4);
+    if (wide) {
+        if constexpr (!CHAIN) {
+            if (q_per_kv == 1) PARROT_FUSED_GO(1, 16);
+            if (q_per_kv == 2) PARROT_FUSED_GO(2, 16);
+            PARROT_FUSED_GO(4, 16);
+        }
+    }
+    if (q_per_kv == 1) PARROT_FUSED_GO(1, kAttnWaves);
+    if (q_per_kv == 2) PARROT_FUSED_GO(2, kAttnWaves);
+    PARROT_FUSED_GO(4, kAttnWaves);
 #undef PARROT_FUSED_GO
 }
 

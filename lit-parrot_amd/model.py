@@ -240,7 +240,7 @@ class GPT(nn.Module):
         global _ACTIVE_PREFETCHER
         M = ws.M
         ops.embedding(self.transformer.wte.weight.data, tokens, tok_pos, M, ws.x)
-        nsplit = ops.attn_nsplit(self.config.n_query_groups, S, self.config.q_per_kv)
+        nsplit = ops.attn_nsplit(self.config.n_query_groups, S, self.config.q_per_kv, M)
         if chain is not None:  # single-token step as chained launches on two streams (ops.Chain)
             if M != 1 or rope_local:
                 raise ParrotHipError("chained step: one token at a time")
@@ -376,7 +376,7 @@ class Block(nn.Module):
                 kc, vc = (torch.empty((c.n_query_groups, S, c.head_size), dtype=torch.bfloat16, device=x.device) for _ in range(2))
                 pos = ws.zero_pos
             ws.x.copy_(x[b])
-            self.run_rows(ws, pos, S, kc, vc, (cos, sin), ops.attn_nsplit(c.n_query_groups, S), rope_local=True)
+            self.run_rows(ws, pos, S, kc, vc, (cos, sin), ops.attn_nsplit(c.n_query_groups, S, c.q_per_kv, T), rope_local=True)
             out[b].copy_(ws.x)
         return out, kv_cache
 
@@ -422,7 +422,7 @@ class CausalSelfAttention(nn.Module):
                 S = T
                 kc, vc = (torch.empty((c.n_query_groups, S, c.head_size), dtype=torch.bfloat16, device=x.device) for _ in range(2))
                 pos = ws.zero_pos
-            self.run_rows(ws, x[b].contiguous(), pos, S, kc, vc, (cos, sin), ops.attn_nsplit(c.n_query_groups, S), True)
+            self.run_rows(ws, x[b].contiguous(), pos, S, kc, vc, (cos, sin), ops.attn_nsplit(c.n_query_groups, S, c.q_per_kv, T), True)
             _linear(self.proj, ws.y, out[b])
         return out, kv_cache
 

@@ -282,11 +282,17 @@ def rope_kvappend(qkv: torch.Tensor, cos: torch.Tensor, sin: torch.Tensor, n_ele
                                                ptr(v_cache), stream()), "parrot_qkv_rope_kvappend")
 
 
-def attn_nsplit(n_groups: int, S: int, q_per_kv: int = 1) -> int:
-    """Sequence splits of the decode-attention kernel: about 32 keys per workgroup (two row batches per wave at
-    head size 128), bounded by ~1024 workgroups per launch (groups x head chunks x splits) and 64 splits."""
+def attn_nsplit(n_groups: int, S: int, q_per_kv: int = 1, M: int = 1) -> int:
+    """Sequence splits of the decode-attention kernels.
+
+    Single new token (fused kernel, 16 waves per workgroup): one workgroup walks up to ~1k keys by itself, so windows up
+    to 1024 take no split at all (no partials / ticket / second pass) and longer ones ceil(S / 1024) splits.
+    Several rows (prefill kernel, 4 waves): about 32 keys per workgroup, bounded by ~1024 workgroups per row and 64 splits."""
     chunks = (q_per_kv + 3) // 4 if q_per_kv > 2 else 1
-    return max(1, min(S // 32, max(1, 1024 // (n_groups * chunks)), 64))
+    cap = max(1, 1024 // (n_groups * chunks))
+    if M == 1:
+        return max(1, min(-(-S // 1024), cap, 64))
+    return max(1, min(S // 32, cap, 64))
 
 
 def attn_workspace(M: int, n_head: int, hs: int, nsplit: int, device) -> torch.Tensor:

@@ -430,10 +430,11 @@ def test_norm_fused_into_linear_equals_norm_then_linear(kind, M, K):
 
 
 @pytest.mark.parametrize("n_groups,q_per_kv,hs,n_elem", ATTN_SHAPES)
-@pytest.mark.parametrize("S,nsplit", [(40, 1), (96, 3), (300, 8)])
+@pytest.mark.parametrize("S,nsplit", [(40, 1), (96, 3), (300, 8), (300, 1), (700, 2), (1500, 1)])
 def test_fused_decode_attention_equals_the_three_kernel_path(n_groups, q_per_kv, hs, n_elem, S, nsplit):
-    """parrot_attn_fused_decode == rope_kvappend + attn_decode (+ combine), bit for bit, including the cache contents,
-    over a prefill and a run of single-token steps that wraps around the ring."""
+    """parrot_attn_fused_decode == rope_kvappend + attn_decode (+ combine): the cache contents bit for bit, the heads up
+    to the grouping of the softmax merge (the fused kernel merges row slots inside a wave with shuffles, and runs 16 waves
+    per workgroup when a split is long), over a prefill and a run of single-token steps that wraps around the ring."""
     g = gen(22)
     n_head, width = n_groups * q_per_kv, n_groups * (q_per_kv + 2) * hs
     cos, sin = (t.to(DEV) for t in om.rope_tables(2048, n_elem, BF, math_dtype=BF))
@@ -454,7 +455,9 @@ def test_fused_decode_attention_equals_the_three_kernel_path(n_groups, q_per_kv,
         ops.attn_decode(q, pos_d, kc1, vc1, n_groups, q_per_kv, hs, S, nsplit, ws1, y1)
         ops.attn_fused_decode(qkv, cos, sin, n_elem, pos_d, kc2, vc2, n_groups, q_per_kv, hs, S, nsplit, ws2, tickets, y2)
         assert torch.equal(kc1, kc2) and torch.equal(vc1, vc2), f"cache differs at pos {pos}"
-        assert torch.equal(y1, y2), f"fused attention differs at pos {pos}: max {float((y1.float() - y2.float()).abs().max())}"
+        d = (y1.float() - y2.float()).abs()
+        assert float(d.max()) <= 2 ** -7 * max(1.0, float(y1.float().abs().max())), f"fused attention differs at pos {pos}: max {float(d.max())}"
+        assert float((d == 0).float().mean()) > 0.9, f"pos {pos}: only {float((d == 0).float().mean()):.3f} of the outputs identical"
         assert int(tickets.abs().sum()) == 0, "arrival tickets must be re-armed"
 
 
