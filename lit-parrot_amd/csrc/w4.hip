@@ -94,37 +94,35 @@ w4_repack_kernel(uint8_t* __restrict__ qref, bf16_t* __restrict__ scales, bf16_t
 // ------------------------------------------------------------------------------------------ GEMV
 constexpr int kMaxRows = 16;  // rows per workgroup
 
-// diagnostic stamps (tools/microbench.py --stamps): 100 MHz clock of a few workgroups at phase boundaries.
-// COMPILE-TIME ONLY (-DPARROT_W4_STAMPS): reading the stamp pointer is a global load, and the s_waitcnt vmcnt(0) the
-// compiler puts behind it also waits for every weight load in flight - a run-time switch in front of the dot loop
-// serialises "all weights arrived" -> "first dot product" in the product build too (measured: +2.5 us per launch).
-#ifdef PARROT_W4_STAMPS
-__device__ unsigned long long* g_w4_dbg = nullptr;
-__device__ __forceinline__ void w4_stamp(int i) {
-    if (g_w4_dbg != nullptr && threadIdx.x == 0 && (blockIdx.x == 0 || blockIdx.x == gridDim.x / 2 || blockIdx.x == gridDim.x - 1)) {
+// diagnostic stamps (tools/microbench.py --stamps): 100 MHz clock of a few workgroups at phase boundaries.  The buffer
+// pointer is a KERNEL ARGUMENT (scalar load): an earlier version read it from a __device__ global, and the
+// s_waitcnt vmcnt(0) behind that vector load also waited for every weight load in flight - a diagnostic switch in
+// front of the dot loop serialised "all weights arrived" -> "first dot product" in every launch (+2.5 us each).
+__device__ __forceinline__ void w4_stamp(unsigned long long* dbg, int i) {
+    if (dbg != nullptr && threadIdx.x == 0 && (blockIdx.x == 0 || blockIdx.x == gridDim.x / 2 || blockIdx.x == gridDim.x - 1)) {
         const int b = blockIdx.x == 0 ? 0 : (blockIdx.x == gridDim.x - 1 ? 2 : 1);
-        g_w4_dbg[b * 8 + i] = __builtin_amdgcn_s_memrealtime();
+        dbg[b * 8 + i] = __builtin_amdgcn_s_memrealtime();
     }
 }
-#else
-__device__ __forceinline__ void w4_stamp(int) {}
-#endif
+static unsigned long long* g_w4_dbg_host = nullptr;  // set by parrot_tune_w4_stamps
 
-// Workgroup shape: nslabs x wps waves.  Wave (slab c, j) streams slab c of row group j: RU consecutive rows whose loads
-// are all issued before the first use.  The activations (and the optional norm of them) are prepared ONCE per workgroup
-// and shared by its wps row groups: that is what makes a fused norm affordable (a 2-wave workgroup would re-normalise
-// 2 x 2048 activations for only 8 output rows).  MAXW = waves the build allows (8 -> 256 VGPRs, 16 -> 128).
+// Workgroup shape: nslabs x wps waves.  Wave (slab c, j) streams slab c of row group j: RU consecutive rows.  The
+// activations (and the optional norm of them) are prepared ONCE per workgroup and shared by its row groups and by the
+// `iters` batches of rows it walks (batch t of workgroup b = rows of workgroup-sized block b + t * gridDim.x): the host
+// sizes the grid to what is resident at once, so that no workgroup starts late and pays the activation / norm chain
+// behind everybody else's weight stream (measured on lm_head: a 4th-round workgroup entered at +11 us and had its norm
+// ready 6.5 us later).  MAXW = waves the build allows (8 -> 256 VGPRs, 16 -> 128).
 template <int M, bool DUAL, int RU, int MAXW>
 __global__ void __launch_bounds__(MAXW * 64)
 w4_gemv_kernel(const uint4* __restrict__ W, const uint4* __restrict__ W2, const bf16_t* __restrict__ x, int ldx,
                const bf16_t* __restrict__ bias, const bf16_t* residual, int ldr, bf16_t* out, int ldo, int N, int K,
-               int wps, int epi, NormArgs na, W4Plan plan) {
+               int wps, int epi, int iters, NormArgs na, W4Plan plan, unsigned long long* dbg, int knob) {
     constexpr int NW = DUAL ? 2 : 1;
     extern __shared__ __attribute__((aligned(16))) unsigned char w4_smem[];  // normalised activations [M][K] bf16 (norm only)
-    __shared__ float red[MAXW][RU * M * NW];
+    __shared__ float red[2][MAXW][RU * M * NW];  // double-buffered over the batches: one barrier per batch
     __shared__ float stat[16];
 
-    w4_stamp(0);
+    w4_stamp(dbg, 0);
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int nwaves = plan.nslabs * wps;
@@ -135,8 +133,7 @@ w4_gemv_kernel(const uint4* __restrict__ W, const uint4* __restrict__ W2, const 
     const int gslice = sl.slice0 + lslice;
     const int gl = gslice / plan.Gs - sl.g0;
     const int64_t row16 = plan.row16;
-    const int wg_row0 = blockIdx.x * (wps * RU);
-    const int r0 = wg_row0 + j * RU;  // first row of this wave's group
+    const int R = wps * RU;  // rows per workgroup and batch
 
     // Load order matters because vmcnt retires in order: first the small L2-resident operands (activations, norm
     // parameters), then the weights.  The prologue then only waits for the former while the HBM stream is running.
@@ -160,37 +157,59 @@ w4_gemv_kernel(const uint4* __restrict__ W, const uint4* __restrict__ W2, const 
             }
         }
     } else {
-        // cooperative: thread t owns chunks t, t + nthreads, ... of every row (and of the norm parameters)
+        // cooperative: thread t owns chunks t, t + nthreads, ... of every row (and of the norm parameters);
+        // rounds past the row (a workgroup-uniform condition) are skipped altogether, not computed on zeros
 #pragma unroll
         for (int it = 0; it < kMaxChunkIt; ++it) {
-            const int c = threadIdx.x + it * nthreads;
-            const int cc = c < chunks ? c : chunks - 1;
-            cw[it] = reinterpret_cast<const uint4*>(na.weight)[cc];
-            cb[it] = make_uint4(0, 0, 0, 0);
-            if (na.kind == 2 && na.bias != nullptr) cb[it] = reinterpret_cast<const uint4*>(na.bias)[cc];
+            cw[it] = cb[it] = make_uint4(0, 0, 0, 0);
 #pragma unroll
-            for (int m = 0; m < M; ++m) {
-                cx[m][it] = reinterpret_cast<const uint4*>(x + (int64_t)m * ldx)[cc];
-                if (c >= chunks) cx[m][it] = make_uint4(0, 0, 0, 0);
+            for (int m = 0; m < M; ++m) cx[m][it] = make_uint4(0, 0, 0, 0);
+            if (it * nthreads < chunks) {
+                const int c = threadIdx.x + it * nthreads;
+                const int cc = c < chunks ? c : chunks - 1;
+                cw[it] = reinterpret_cast<const uint4*>(na.weight)[cc];
+                if (na.kind == 2 && na.bias != nullptr) cb[it] = reinterpret_cast<const uint4*>(na.bias)[cc];
+#pragma unroll
+                for (int m = 0; m < M; ++m) cx[m][it] = reinterpret_cast<const uint4*>(x + (int64_t)m * ldx)[cc];
+                // (a thread past the row inside a live round holds a clamped copy: masked where it is used, so that
+                //  the loads of all rounds are in flight together instead of load -> wait -> select per round)
             }
         }
     }
 
     uint4 w[NW][RU];
     uint32_t mt[NW][RU];
-#pragma unroll
-    for (int u = 0; u < RU; ++u) {
-        const int64_t row = min(r0 + u, N - 1);
-        const uint4* rec = W + row * row16;
-        // weights are read exactly once per token: non-temporal loads keep them from displacing the activations in L2
-        w[0][u] = load_nt16(rec + sl.w_off16 + lslice);
-        mt[0][u] = load_nt4(reinterpret_cast<const uint32_t*>(rec + sl.meta_off16) + gl);
-        if (DUAL) {
-            const uint4* rec2 = W2 + row * row16;
-            w[1][u] = load_nt16(rec2 + sl.w_off16 + lslice);
-            mt[1][u] = load_nt4(reinterpret_cast<const uint32_t*>(rec2 + sl.meta_off16) + gl);
-        }
+    // Rolling window of weight loads.  A CU accepts only so many vector-memory instructions in flight; a wave that issues
+    // all its rows at once sits in the ISSUE of those loads until earlier ones (its own and the other workgroups' of the
+    // CU) have returned at HBM speed, and everything behind them in program order - the fused norm above all - waits
+    // too.  About 3 KB per wave in flight already covers the HBM latency-bandwidth product, so PRIME rows are requested
+    // up front and row u + PRIME (of this batch, or of the next one) is requested right before row u is consumed.
+    constexpr int PRIME = (RU * NW >= 8) ? 3 : 2;
+    static_assert(PRIME <= RU, "rolling window longer than a batch");
+    // first row of this wave in batch T; batches past the matrix are clamped to the last row (loaded, never stored)
+#define W4_ROW0(T) (((int)blockIdx.x + (T) * (int)gridDim.x) * R + j * RU)
+#define W4_ISSUE_ROW(T, U)                                                                            \
+    {                                                                                                 \
+        const int64_t row_ = min(W4_ROW0(T) + (U), N - 1);                                            \
+        const uint4* rec_ = W + row_ * row16;                                                         \
+        /* weights are read exactly once per token: non-temporal loads keep them out of the way of the activations in L2 */ \
+        w[0][U] = load_nt16(rec_ + sl.w_off16 + lslice);                                              \
+        mt[0][U] = load_nt4(reinterpret_cast<const uint32_t*>(rec_ + sl.meta_off16) + gl);            \
+        if (DUAL) {                                                                                   \
+            const uint4* rec2_ = W2 + row_ * row16;                                                   \
+            w[1][U] = load_nt16(rec2_ + sl.w_off16 + lslice);                                         \
+            mt[1][U] = load_nt4(reinterpret_cast<const uint32_t*>(rec2_ + sl.meta_off16) + gl);       \
+        }                                                                                             \
     }
+    if (na.kind != 0) {  // EXPERIMENT knob: what to do between the activation requests and the first weight requests
+        if (knob == 1) __builtin_amdgcn_s_sleep(20);
+        if (knob == 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (knob == 3) __syncthreads();
+        if (knob == 4) __builtin_amdgcn_s_sleep(60);
+    }
+#pragma unroll
+    for (int u = 0; u < PRIME; ++u) W4_ISSUE_ROW(0, u)
+    asm volatile("" ::: "memory");  // keep the remaining requests below the prologue
 
     if (na.kind != 0) {  // fused RMSNorm / LayerNorm of the input rows, once per workgroup, through LDS
         uint4* xn = reinterpret_cast<uint4*>(w4_smem);
@@ -199,9 +218,13 @@ w4_gemv_kernel(const uint4* __restrict__ W, const uint4* __restrict__ W2, const 
             float s1 = 0.f;
 #pragma unroll
             for (int it = 0; it < kMaxChunkIt; ++it) {
-                const uint32_t dw[4] = {cx[m][it].x, cx[m][it].y, cx[m][it].z, cx[m][it].w};
+                if (it * nthreads < chunks) {  // uniform
+                    const uint32_t dw[4] = {cx[m][it].x, cx[m][it].y, cx[m][it].z, cx[m][it].w};
+                    float t = 0.f;
 #pragma unroll
-                for (int i = 0; i < 4; ++i) s1 += norm_stat1(dw[i], na.kind);  // chunks past the row hold zeros
+                    for (int i = 0; i < 4; ++i) t += norm_stat1(dw[i], na.kind);
+                    s1 += (threadIdx.x + it * nthreads < chunks) ? t : 0.f;
+                }
             }
             s1 = block_sum_waves(s1, stat, nwaves);
             float mean = 0.f, r;
@@ -257,41 +280,60 @@ w4_gemv_kernel(const uint4* __restrict__ W, const uint4* __restrict__ W2, const 
         for (int i = 0; i < 16; ++i) s += bflo(xr[m][i]) + bfhi(xr[m][i]);
         xs[m] = s;
     }
-    w4_stamp(1);
+    w4_stamp(dbg, 1);
 
+    for (int t = 0; t < iters; ++t) {
+        float(*rd)[RU * M * NW] = red[t & 1];
 #pragma unroll
-    for (int u = 0; u < RU; ++u) {
+        for (int u = 0; u < RU; ++u) {
+            // request row u + PRIME: of this batch, or - across the batch boundary - of the next one
+            if (u + PRIME < RU) {
+                W4_ISSUE_ROW(t, u + PRIME)
+            } else if (t + 1 < iters) {
+                W4_ISSUE_ROW(t + 1, u + PRIME - RU)
+            }
+            asm volatile("" ::: "memory");
+            // consume row u (its registers are re-filled PRIME steps later at the earliest ... by row u + PRIME - RU of the
+            // next batch, which is only requested after this use)
+            float part[NW][M];
 #pragma unroll
-        for (int q = 0; q < NW; ++q) {
-            const float s = bflo(mt[q][u]);
-            const float zz = 128.0f + bfhi(mt[q][u]);
+            for (int q = 0; q < NW; ++q) {
+                const float s = bflo(mt[q][u]);
+                const float zz = 128.0f + bfhi(mt[q][u]);
 #pragma unroll
-            for (int m = 0; m < M; ++m) {
-                const float p = w4_slice_dot(w[q][u], xr[m]);
-                const float v = wave_sum_to_lane63(s * (p - zz * xs[m]));
-                if (lane == 63) red[wave][(u * M + m) * NW + q] = v;
+                for (int m = 0; m < M; ++m) {
+                    const float p = w4_slice_dot(w[q][u], xr[m]);
+                    part[q][m] = wave_sum_to_lane63(s * (p - zz * xs[m]));
+                }
+            }
+#pragma unroll
+            for (int q = 0; q < NW; ++q)
+#pragma unroll
+                for (int m = 0; m < M; ++m)
+                    if (lane == 63) rd[wave][(u * M + m) * NW + q] = part[q][m];
+        }
+        if (t == 0) w4_stamp(dbg, 2);
+        __syncthreads();
+        if (t == 0) w4_stamp(dbg, 3);
+        // epilogue: one thread per (row of the batch, m); sums the slabs in a fixed order
+        if ((int)threadIdx.x < R * M) {
+            const int m = threadIdx.x % M, ur = threadIdx.x / M;
+            const int jj = ur / RU, u = ur % RU;
+            const int col = ((int)blockIdx.x + t * (int)gridDim.x) * R + ur;
+            if (col < N) {
+                float a0 = 0.f, a1 = 0.f;
+                for (int c = 0; c < plan.nslabs; ++c) {
+                    a0 += rd[c * wps + jj][(u * M + m) * NW];
+                    if (DUAL) a1 += rd[c * wps + jj][(u * M + m) * NW + 1];
+                }
+                out[(int64_t)m * ldo + col] =
+                    apply_epilogue(epi, a0, a1, bias, residual ? residual + (int64_t)m * ldr : nullptr, col);
             }
         }
     }
-    w4_stamp(2);
-    __syncthreads();
-    w4_stamp(3);
-    // epilogue: one thread per (row of the workgroup, m); sums the slabs in a fixed order
-    if ((int)threadIdx.x < wps * RU * M) {
-        const int m = threadIdx.x % M, ur = threadIdx.x / M;
-        const int jj = ur / RU, u = ur % RU;
-        const int col = wg_row0 + ur;
-        if (col < N) {
-            float a0 = 0.f, a1 = 0.f;
-            for (int c = 0; c < plan.nslabs; ++c) {
-                a0 += red[c * wps + jj][(u * M + m) * NW];
-                if (DUAL) a1 += red[c * wps + jj][(u * M + m) * NW + 1];
-            }
-            out[(int64_t)m * ldo + col] =
-                apply_epilogue(epi, a0, a1, bias, residual ? residual + (int64_t)m * ldr : nullptr, col);
-        }
-    }
-    w4_stamp(4);
+#undef W4_ISSUE_ROW
+#undef W4_ROW0
+    w4_stamp(dbg, 4);
 }
 
 // ------------------------------------------------------------------------------------------ streaming GEMV (M = 1)
@@ -508,6 +550,8 @@ w4_stream_kernel(const uint4* __restrict__ W, const uint4* __restrict__ W2, cons
 
 static int g_stream_wgs_per_cu_x2 = 0;  // tuning hook: workgroups per 128 CUs ... (0 = heuristic)
 
+static int g_w4_knob = 0;  // experiment hook
+static int g_resident_override = 0;  // tuning hook: workgroups per launch before a workgroup walks several batches
 static int g_wps_override = 0;  // tuning hook (tools/microbench.py): row groups per workgroup, 0 = heuristic
 
 // row groups per workgroup: aim at ~640 workgroups per launch, bounded by the waves the build allows
@@ -545,10 +589,15 @@ static int w4_gemv_launch_v(const void* packed, const void* packed2, const void*
         lds = (size_t)M * K * 2;
         PARROT_UNSUPPORTED(lds <= 64 * 1024, "w4_gemv: fused norm needs %zu B of LDS", lds);
     }
-    const dim3 grid((N + R - 1) / R), block(nthreads);
+    // grid = what is resident at once (4 waves per SIMD with either build), every workgroup walks `iters` batches of rows
+    const int batches = (N + R - 1) / R;
+    int resident = 256 * (16 / (plan.nslabs * wps) > 0 ? 16 / (plan.nslabs * wps) : 1);
+    if (g_resident_override > 0) resident = g_resident_override;
+    const int iters = (batches + resident - 1) / resident;
+    const dim3 grid((batches + iters - 1) / iters), block(nthreads);
     return launch(DUAL ? K_W4_GEMV_DUAL : K_W4_GEMV, w4_gemv_kernel<M, DUAL, RU, MAXW>, grid, block, lds, st,
                   (const uint4*)packed, (const uint4*)packed2, (const bf16_t*)x, ldx, (const bf16_t*)bias,
-                  (const bf16_t*)residual, ldr, (bf16_t*)out, ldo, N, K, wps, epi, na, plan);
+                  (const bf16_t*)residual, ldr, (bf16_t*)out, ldo, N, K, wps, epi, iters, na, plan, g_w4_dbg_host, g_w4_knob);
 }
 
 static int g_use_stream = 0;  // the pipelined kernel measured no faster than the burst kernel (tools/microbench.py); kept selectable
@@ -615,7 +664,7 @@ static int w4_gemv_launch(const void* packed, const void* packed2, const void* x
                     : w4_stream_launch<false, 4, 16>(packed, packed2, x, bias, residual, out, N, K, epi, na, plan, st);
     }
     // rows in flight per wave: 8 for the single-row decode kernel, fewer when a second weight or more rows share the registers
-    constexpr int RU1 = (M == 1) ? 8 : 4;
+    constexpr int RU1 = (M == 1) ? 8 : 4;  // (16 / 8 rows in flight measured slower: occupancy drops to 3 waves per SIMD)
     constexpr int RU2 = (M <= 2) ? 4 : 2;
 #define PARROT_W4_GO(DUALV, RUV, MAXWV) \
     return w4_gemv_launch_v<M, DUALV, RUV, MAXWV>(packed, packed2, x, ldx, bias, residual, ldr, out, ldo, N, K, epi, na, plan, st)
@@ -636,20 +685,23 @@ extern "C" {
 
 // tuning hook, not part of the public header: rows of output per workgroup (0 = heuristic)
 int parrot_tune_w4_stamps(void* dbg24_u64) {  // diagnostic: device buffer of 24 uint64, or NULL to switch off
-#ifdef PARROT_W4_STAMPS
-    unsigned long long* p = (unsigned long long*)dbg24_u64;
-    hipError_t e = hipMemcpyToSymbol(HIP_SYMBOL(g_w4_dbg), &p, sizeof(p));
-    return e == hipSuccess ? PARROT_OK : hip_fail(e, "hipMemcpyToSymbol");
-#else
-    (void)dbg24_u64;
-    set_error("w4 stamps are a compile-time diagnostic: rebuild with -DPARROT_W4_STAMPS");
-    return PARROT_EUNSUPPORTED;
-#endif
+    g_w4_dbg_host = (unsigned long long*)dbg24_u64;
+    return PARROT_OK;
 }
 
 int parrot_tune_w4_stream(int use_stream, int wgs_per_128_cus) {  // diagnostic / tuning
     g_use_stream = use_stream;
     g_stream_wgs_per_cu_x2 = wgs_per_128_cus;
+    return PARROT_OK;
+}
+
+int parrot_tune_w4_knob(int knob) {
+    g_w4_knob = knob;
+    return PARROT_OK;
+}
+
+int parrot_tune_w4_resident(int workgroups) {  // 0 = derive from the workgroup shape
+    g_resident_override = workgroups > 0 ? workgroups : 0;
     return PARROT_OK;
 }
 
