@@ -171,8 +171,6 @@ def main() -> None:
     ap.add_argument("--workload", default="llama2-7b-int4", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=20.0)
-    ap.add_argument("--chained", type=int, default=None, choices=(0, 1),
-                    help="single-token step as chained launches (default: the library's default, PARROT_CHAINED)")
     args = ap.parse_args()
 
     rank, local, world = rank_env()
@@ -204,11 +202,6 @@ def main() -> None:
     t_build = time.perf_counter() - t_build
 
     with torch.no_grad():
-        if args.chained is not None:
-            import importlib
-
-            gen_base = importlib.import_module("lit_parrot_amd.generate.base")  # (L.generate is the function)
-            gen_base.CHAINED_DEFAULT = bool(args.chained)
         sess = _session(model, total, total, greedy=True)
         t_pre = time.perf_counter()
         logits = sess.prefill(prompt.to(device))
@@ -225,8 +218,6 @@ def main() -> None:
         barrier(world, device)
         elapsed = time.perf_counter() - t0
         elapsed_max, units = max_over_ranks(elapsed, args.steps, world, device)
-        if sess.chain is not None:
-            sess.chain.check()  # no in-kernel wait timed out
         pos_end = int(sess.pos.item())
         assert pos_end == T + args.warmup + args.steps, (pos_end, T, args.warmup, args.steps)
 
@@ -271,8 +262,7 @@ def main() -> None:
         "data": "synthetic",
         "config": {"workload": f"{cfg_name} {mode or 'bf16'} single-stream decode, {T}-token prompt, random-init weights",
                    "prompt_tokens": T, "replicas": world, "parallelism": f"replicas x{world} (no collective)",
-                   "graph": "hipGraph replay per token",
-                   "step": "chained launches (2 streams, in-kernel arrival counters)" if sess.chain is not None else "one launch after another"},
+                   "graph": "hipGraph replay per token"},
         "roofline": roofline,
         "step_roofline": {"bound": "hbm", "achieved": step_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                           "frac": step_gbs / HBM_PEAK_GBS, "bytes_per_token": w_bytes + kv_bytes,

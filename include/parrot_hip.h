@@ -150,38 +150,6 @@ int parrot_attn_fused_decode(const void* qkv, const void* rope_cos, const void* 
                              void* workspace, void* tickets, void* k_cache, void* v_cache, void* y,
                              void* stream);
 
-/* ---- chained launches of the single-token step ---------------------------------------------------------
- * The per-token work of GPT.forward (lit_gpt/model.py:83-103) is a strict sequence of ~5 launches per Block, each a
- * few microseconds long, so launch ramp and drain dominate.  A *chained* launch is put on the other of two streams than
- * its predecessor: it starts while the predecessor runs, requests what does not depend on it (weights, norm parameters,
- * K/V rows), waits IN the kernel for the predecessor's arrival counters, then reads the activations.  The caller
- *   - alternates two streams, launch i on stream i % 2, in the sequential order of the reference's forward;
- *   - zeroes counters[i] (PARROT_CHAIN_COUNTER_WORDS uint32 per launch) and *err before each token;
- *   - passes wait = counters[i-1], wait_target = the `workgroups` the previous call returned, signal = counters[i].
- * Launch shapes are restricted so that two adjacent launches are always co-resident on the device (PARROT_EUNSUPPORTED
- * otherwise); a wait that still exceeds 20 ms sets *err non-zero and lets the grid drain - the caller checks it.    */
-#define PARROT_CHAIN_COUNTER_WORDS 512
-typedef struct parrot_chain_t {
-    const uint32_t* wait;  /* in: predecessor's counters, NULL for the first launch of a token */
-    uint32_t wait_target;  /* in: predecessor's workgroup count */
-    uint32_t* signal;      /* in: this launch's counters, NULL if nothing waits for it in-kernel */
-    uint32_t* err;         /* in: device word shared by the whole chain */
-    uint32_t workgroups;   /* out: workgroups that will add 1 to `signal` */
-    uint64_t* stamps;      /* in: NULL, or 4 device uint64 receiving workgroup 0's 100 MHz clock at: start, wait done,
-                              compute done, signalled (diagnostic, tools/chain_timeline.py) */
-} parrot_chain_t;
-/* parrot_w4_gemv for one row (M = 1, contiguous x / residual / out) as a chained launch */
-int parrot_w4_gemv_chained(const void* packed, const void* packed2, const void* x, const void* bias,
-                           const void* residual, void* out, int N, int K, int group, int epilogue,
-                           const parrot_norm_t* norm, parrot_chain_t* chain, void* stream);
-/* PARROT_OK when a Linear of this shape (with or without a fused norm) has a chained form, else PARROT_EUNSUPPORTED */
-int parrot_w4_gemv_chained_supported(int N, int K, int group, int with_norm);
-/* parrot_attn_fused_decode as a chained launch (n_groups * nsplit * head chunks <= 256 workgroups) */
-int parrot_attn_fused_decode_chained(const void* qkv, const void* rope_cos, const void* rope_sin, int n_elem,
-                                     const int32_t* pos, int n_groups, int q_per_kv, int hs, int S, int nsplit,
-                                     void* workspace, void* tickets, void* k_cache, void* v_cache, void* y,
-                                     parrot_chain_t* chain, void* stream);
-
 /* ---- small ops of the step ----------------------------------------------------------
  * x[m] = wte[tokens[(pos ? *pos : 0) + m]]   (lit_gpt/model.py:99)                    */
 int parrot_embedding(const void* wte, int d, const int64_t* tokens, const int32_t* pos, int M,

@@ -61,14 +61,6 @@ class PkState(C.Structure):  # parrot_pk_state_t
 
 
 
-class ParrotChain(C.Structure):  # parrot_chain_t
-    _fields_ = [("wait", C.c_void_p), ("wait_target", C.c_uint32), ("signal", C.c_void_p), ("err", C.c_void_p),
-                ("workgroups", C.c_uint32), ("stamps", C.c_void_p)]
-
-
-CHAIN_COUNTER_WORDS = 512
-_cp = C.POINTER(ParrotChain)
-
 # name -> (restype, argtypes); must list every function include/parrot_hip.h declares
 SIGNATURES = {
     "parrot_version": (_i, []),
@@ -92,9 +84,6 @@ SIGNATURES = {
     "parrot_attn_workspace_floats": (_i64, [_i, _i, _i, _i]),
     "parrot_attn_decode": (_i, [_vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _i, _vp]),
     "parrot_attn_fused_decode": (_i, [_vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
-    "parrot_w4_gemv_chained_supported": (_i, [_i, _i, _i, _i]),
-    "parrot_w4_gemv_chained": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _np, _cp, _vp]),
-    "parrot_attn_fused_decode_chained": (_i, [_vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _cp, _vp]),
     "parrot_pk_fill_w4": (_i, [C.POINTER(PkOp), _i, _i, _i]),
     "parrot_pk_step": (_i, [C.POINTER(PkState), _vp]),
     "parrot_embedding": (_i, [_vp, _i, _vp, _vp, _i, _vp, _i, _vp]),

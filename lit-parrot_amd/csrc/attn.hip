@@ -226,17 +226,12 @@ __device__ __forceinline__ float load_agent(const float* p) {
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-// CHAIN = true: chained-launch form (parrot_common.h).  The RoPE table entries and the first K/V rows are requested,
-// then the workgroup waits for the QKV launch in-kernel and reads its group's rows with agent-scope loads; y is written
-// with write-through stores and every workgroup signals once its part (partials, or the merged heads) has drained.
-// WAVES = 4 or 16 wavefronts per workgroup: with 16, one workgroup walks 64 (hs 128) .. 256 (hs 32) keys per step, so
-// that contexts up to ~1k keys need no cross-workgroup split at all (no partials, no ticket, no second pass).
-template <int HS, int HQ, int WAVES, bool CHAIN>
+template <int HS, int HQ, int WAVES>
 __global__ void __launch_bounds__(WAVES * 64)
-attn_fused_decode_kernel(const bf16_t* qkv, const __half* __restrict__ rope_cos,
+attn_fused_decode_kernel(const bf16_t* __restrict__ qkv, const __half* __restrict__ rope_cos,
                          const __half* __restrict__ rope_sin, int n_elem, const int32_t* __restrict__ pos_ptr,
                          bf16_t* __restrict__ k_cache, bf16_t* __restrict__ v_cache, int n_groups, int q_per_kv, int S,
-                         int nsplit, float* __restrict__ ws, unsigned int* __restrict__ tickets, bf16_t* y, ChainArgs ca) {
+                         int nsplit, float* __restrict__ ws, unsigned int* __restrict__ tickets, bf16_t* __restrict__ y) {
     constexpr int LPR = HS / 8;
     constexpr int RPW = 64 / LPR;
     __shared__ float sh_acc[HQ][WAVES][HS];  // one merged state per wave
@@ -275,11 +270,11 @@ attn_fused_decode_kernel(const bf16_t* qkv, const __half* __restrict__ rope_cos,
         rc[it] = 1.f;
         if (idx < n_rope_elems) {
             const int t = idx / HS, d = idx % HS;
-            if (!CHAIN) rx[it] = bf2f(grp[idx]);
+            rx[it] = bf2f(grp[idx]);
             if (t <= q_per_kv && d < n_elem) {
                 rc[it] = __half2float(rope_cos[(int64_t)pos * n_elem + d]);
                 rs[it] = __half2float(rope_sin[(int64_t)pos * n_elem + d]);
-                if (!CHAIN) ro[it] = d < half_n ? -bf2f(grp[idx + half_n]) : bf2f(grp[idx - half_n]);
+                ro[it] = d < half_n ? -bf2f(grp[idx + half_n]) : bf2f(grp[idx - half_n]);
             }
         }
     }
@@ -289,21 +284,6 @@ attn_fused_decode_kernel(const bf16_t* qkv, const __half* __restrict__ rope_cos,
         const int sc = min(s_first + sub, s_end - 1);
         kv_cur = kc[(int64_t)sc * LPR + dl];
         vv_cur = vc[(int64_t)sc * LPR + dl];
-    }
-    if (CHAIN) {
-        chain_stamp(ca, 0);
-        chain_wait(ca);
-        chain_stamp(ca, 1);
-#pragma unroll
-        for (int it = 0; it < ROPE_IT; ++it) {
-            const int idx = threadIdx.x + it * WAVES * 64;
-            if (idx < n_rope_elems) {
-                const int t = idx / HS, d = idx % HS;
-                rx[it] = bf2f(ld_agent16(grp + idx));
-                if (t <= q_per_kv && d < n_elem)
-                    ro[it] = d < half_n ? -bf2f(ld_agent16(grp + idx + half_n)) : bf2f(ld_agent16(grp + idx - half_n));
-            }
-        }
     }
 
     // ---- split + RoPE of this group's rows (reference model.py:208-232): x*cos + rotate_half(x)*sin, each product and
@@ -429,10 +409,7 @@ attn_fused_decode_kernel(const bf16_t* qkv, const __half* __restrict__ rope_cos,
                 }
                 const int head = g * q_per_kv + h0 + hh;
                 if (nsplit == 1) {
-                    if (CHAIN)
-                        st_agent16(y + (int64_t)head * HS + d, f2bf(a / l));
-                    else
-                        y[(int64_t)head * HS + d] = f2bf(a / l);
+                    y[(int64_t)head * HS + d] = f2bf(a / l);
                 } else {
                     float* p = ws + ((int64_t)head * nsplit + split) * (HS + 2);
                     store_agent(p + d, a);
@@ -444,15 +421,7 @@ attn_fused_decode_kernel(const bf16_t* qkv, const __half* __restrict__ rope_cos,
             }
         }
     }
-    const int wg_linear = (blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x;
-    if (nsplit == 1) {
-        if (CHAIN) {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            __syncthreads();
-            if (threadIdx.x == 0) chain_signal(ca, wg_linear);
-        }
-        return;
-    }
+    if (nsplit == 1) return;
     // ---- arrival ticket: the last workgroup of this group merges the splits
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every storing wave drains its write-through stores
     __syncthreads();
@@ -462,11 +431,7 @@ attn_fused_decode_kernel(const bf16_t* qkv, const __half* __restrict__ rope_cos,
         if (sh_last) __hip_atomic_store(&tickets[g * gridDim.z + blockIdx.z], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // re-arm
     }
     __syncthreads();
-    if (!sh_last) {
-        chain_stamp(ca, 2);
-        if (CHAIN && threadIdx.x == 0) chain_signal(ca, wg_linear);  // its partials are already visible
-        return;
-    }
+    if (!sh_last) return;
     for (int idx = threadIdx.x; idx < HQ * HS; idx += WAVES * 64) {
         const int hq = h0 + idx / HS, d = idx % HS;
         if (hq >= q_per_kv) continue;
@@ -481,45 +446,27 @@ attn_fused_decode_kernel(const bf16_t* qkv, const __half* __restrict__ rope_cos,
             l += load_agent(p + t * (HS + 2) + HS + 1) * wgt;
             a += load_agent(p + t * (HS + 2) + d) * wgt;
         }
-        if (CHAIN)
-            st_agent16(y + (int64_t)head * HS + d, f2bf(a / l));
-        else
-            y[(int64_t)head * HS + d] = f2bf(a / l);
-    }
-    if (CHAIN) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (threadIdx.x == 0) chain_signal(ca, wg_linear);
+        y[(int64_t)head * HS + d] = f2bf(a / l);
     }
 }
 
-template <int HS, bool CHAIN>
+template <int HS>
 static int attn_fused_launch(const void* qkv, const void* cosp, const void* sinp, int n_elem, const int32_t* pos,
                              void* k_cache, void* v_cache, int n_groups, int q_per_kv, int S, int nsplit, void* ws,
-                             void* tickets, void* y, parrot_chain_t* ch, hipStream_t st) {
+                             void* tickets, void* y, hipStream_t st) {
     const int hq = q_per_kv == 1 ? 1 : (q_per_kv == 2 ? 2 : 4);
-    // 16 waves when a split holds more keys than 4 waves cover in two steps; chained launches keep the 4-wave shape
+    // 16 waves when a split holds more keys than 4 waves cover in two steps
     const int per = (S + nsplit - 1) / nsplit;
-    const bool wide = !CHAIN && per > 2 * kAttnWaves * (64 / (HS / 8));
+    const bool wide = per > 2 * kAttnWaves * (64 / (HS / 8));
     const dim3 grid(n_groups, nsplit, (q_per_kv + hq - 1) / hq), block((wide ? 16 : kAttnWaves) * 64);
-    ChainArgs ca{nullptr, 0u, nullptr, nullptr, nullptr};
-    if (CHAIN) {
-        // co-residency rule of chained launches: <= 256 workgroups (4 waves x <= 136 VGPRs, <= 42 KB LDS each)
-        const int64_t wgs = (int64_t)grid.x * grid.y * grid.z;
-        PARROT_UNSUPPORTED(wgs <= 256, "attn_fused_decode_chained: %lld workgroups, at most 256 may be chained", (long long)wgs);
-        ca = ChainArgs{ch->wait, ch->wait_target, ch->signal, ch->err, (unsigned long long*)ch->stamps};
-        ch->workgroups = (uint32_t)wgs;
-    }
 #define PARROT_FUSED_GO(HQV, WV)                                                                                        \
-    return launch(K_ATTN_FUSED, attn_fused_decode_kernel<HS, HQV, WV, CHAIN>, grid, block, 0, st, (const bf16_t*)qkv,   \
+    return launch(K_ATTN_FUSED, attn_fused_decode_kernel<HS, HQV, WV>, grid, block, 0, st, (const bf16_t*)qkv,          \
                   (const __half*)cosp, (const __half*)sinp, n_elem, pos, (bf16_t*)k_cache, (bf16_t*)v_cache, n_groups,   \
-                  q_per_kv, S, nsplit, (float*)ws, (unsigned int*)tickets, (bf16_t*)y, ca)
+                  q_per_kv, S, nsplit, (float*)ws, (unsigned int*)tickets, (bf16_t*)y)
     if (wide) {
-        if constexpr (!CHAIN) {
-            if (q_per_kv == 1) PARROT_FUSED_GO(1, 16);
-            if (q_per_kv == 2) PARROT_FUSED_GO(2, 16);
-            PARROT_FUSED_GO(4, 16);
-        }
+        if (q_per_kv == 1) PARROT_FUSED_GO(1, 16);
+        if (q_per_kv == 2) PARROT_FUSED_GO(2, 16);
+        PARROT_FUSED_GO(4, 16);
     }
     if (q_per_kv == 1) PARROT_FUSED_GO(1, kAttnWaves);
     if (q_per_kv == 2) PARROT_FUSED_GO(2, kAttnWaves);
@@ -570,50 +517,26 @@ int parrot_qkv_rope_kvappend(const void* qkv, int ldqkv, int M, const void* rope
                   n_elem, rope_local, pos, n_groups, q_per_kv, hs, S, (bf16_t*)q_out, (bf16_t*)k_cache, (bf16_t*)v_cache);
 }
 
-static int attn_fused_entry(const char* name, const void* qkv, const void* rope_cos, const void* rope_sin, int n_elem,
-                            const int32_t* pos, int n_groups, int q_per_kv, int hs, int S, int nsplit, void* workspace,
-                            void* tickets, void* k_cache, void* v_cache, void* y, parrot_chain_t* chain, void* stream) {
-    PARROT_REQUIRE(qkv && pos && k_cache && v_cache && y, "%s: null pointer", name);
-    PARROT_REQUIRE(n_groups >= 1 && q_per_kv >= 1 && S >= 1, "%s: bad shape", name);
-    PARROT_UNSUPPORTED(q_per_kv <= kFusedMaxQ, "%s: at most %d query heads per group (got %d)", name, kFusedMaxQ, q_per_kv);
-    PARROT_REQUIRE(n_elem % 2 == 0 && n_elem >= 0 && n_elem <= hs, "%s: bad n_elem=%d", name, n_elem);
-    PARROT_REQUIRE(n_elem == 0 || (rope_cos && rope_sin), "%s: rope tables missing", name);
-    PARROT_REQUIRE(nsplit >= 1 && nsplit <= 65535, "%s: nsplit out of range", name);
-    PARROT_REQUIRE(nsplit == 1 || (workspace && tickets), "%s: workspace and tickets required when nsplit > 1", name);
-    PARROT_REQUIRE(aligned16(qkv) && aligned16(k_cache) && aligned16(v_cache), "%s: 16-byte alignment", name);
-    hipStream_t st = (hipStream_t)stream;
-#define PARROT_FUSED_HS(HSV)                                                                                                  \
-    case HSV:                                                                                                                 \
-        return chain ? attn_fused_launch<HSV, true>(qkv, rope_cos, rope_sin, n_elem, pos, k_cache, v_cache, n_groups, q_per_kv, \
-                                                    S, nsplit, workspace, tickets, y, chain, st)                              \
-                     : attn_fused_launch<HSV, false>(qkv, rope_cos, rope_sin, n_elem, pos, k_cache, v_cache, n_groups,        \
-                                                     q_per_kv, S, nsplit, workspace, tickets, y, nullptr, st)
-    switch (hs) {
-        PARROT_FUSED_HS(32);
-        PARROT_FUSED_HS(64);
-        PARROT_FUSED_HS(128);
-        default: break;
-    }
-#undef PARROT_FUSED_HS
-    set_error("%s: head size %d not built (32, 64, 128)", name, hs);
-    return PARROT_EUNSUPPORTED;
-}
-
 int parrot_attn_fused_decode(const void* qkv, const void* rope_cos, const void* rope_sin, int n_elem, const int32_t* pos,
                              int n_groups, int q_per_kv, int hs, int S, int nsplit, void* workspace, void* tickets,
                              void* k_cache, void* v_cache, void* y, void* stream) {
-    return attn_fused_entry("attn_fused_decode", qkv, rope_cos, rope_sin, n_elem, pos, n_groups, q_per_kv, hs, S, nsplit,
-                            workspace, tickets, k_cache, v_cache, y, nullptr, stream);
-}
-
-int parrot_attn_fused_decode_chained(const void* qkv, const void* rope_cos, const void* rope_sin, int n_elem,
-                                     const int32_t* pos, int n_groups, int q_per_kv, int hs, int S, int nsplit,
-                                     void* workspace, void* tickets, void* k_cache, void* v_cache, void* y,
-                                     parrot_chain_t* chain, void* stream) {
-    PARROT_REQUIRE(chain != nullptr && chain->err != nullptr, "attn_fused_decode_chained: chain descriptor / error word missing");
-    PARROT_REQUIRE(chain->wait == nullptr || chain->wait_target >= 1, "attn_fused_decode_chained: wait without a target");
-    return attn_fused_entry("attn_fused_decode_chained", qkv, rope_cos, rope_sin, n_elem, pos, n_groups, q_per_kv, hs, S,
-                            nsplit, workspace, tickets, k_cache, v_cache, y, chain, stream);
+    PARROT_REQUIRE(qkv && pos && k_cache && v_cache && y, "attn_fused_decode: null pointer");
+    PARROT_REQUIRE(n_groups >= 1 && q_per_kv >= 1 && S >= 1, "attn_fused_decode: bad shape");
+    PARROT_UNSUPPORTED(q_per_kv <= kFusedMaxQ, "attn_fused_decode: at most %d query heads per group (got %d)", kFusedMaxQ, q_per_kv);
+    PARROT_REQUIRE(n_elem % 2 == 0 && n_elem >= 0 && n_elem <= hs, "attn_fused_decode: bad n_elem=%d", n_elem);
+    PARROT_REQUIRE(n_elem == 0 || (rope_cos && rope_sin), "attn_fused_decode: rope tables missing");
+    PARROT_REQUIRE(nsplit >= 1 && nsplit <= 65535, "attn_fused_decode: nsplit out of range");
+    PARROT_REQUIRE(nsplit == 1 || (workspace && tickets), "attn_fused_decode: workspace and tickets required when nsplit > 1");
+    PARROT_REQUIRE(aligned16(qkv) && aligned16(k_cache) && aligned16(v_cache), "attn_fused_decode: 16-byte alignment");
+    hipStream_t st = (hipStream_t)stream;
+    switch (hs) {
+        case 32: return attn_fused_launch<32>(qkv, rope_cos, rope_sin, n_elem, pos, k_cache, v_cache, n_groups, q_per_kv, S, nsplit, workspace, tickets, y, st);
+        case 64: return attn_fused_launch<64>(qkv, rope_cos, rope_sin, n_elem, pos, k_cache, v_cache, n_groups, q_per_kv, S, nsplit, workspace, tickets, y, st);
+        case 128: return attn_fused_launch<128>(qkv, rope_cos, rope_sin, n_elem, pos, k_cache, v_cache, n_groups, q_per_kv, S, nsplit, workspace, tickets, y, st);
+        default: break;
+    }
+    set_error("attn_fused_decode: head size %d not built (32, 64, 128)", hs);
+    return PARROT_EUNSUPPORTED;
 }
 
 int64_t parrot_attn_workspace_floats(int M, int n_head, int hs, int nsplit) {

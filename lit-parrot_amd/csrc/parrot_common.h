@@ -255,78 +255,33 @@ __device__ __forceinline__ bf16_t apply_epilogue_v(int epi, float acc, float acc
     }
     return f2bf(v);
 }
+// the same with the bias and residual ELEMENTS already in registers (requested early, off the kernel's tail)
+__device__ __forceinline__ bf16_t apply_epilogue_vals(int epi, float acc, float acc2, bool has_bias, float bias_v, float res) {
+    float v = acc;
+    if (has_bias) v += bias_v;
+    v = rbf(v);
+    if (epi == PARROT_EPI_RESIDUAL) {
+        v = res + v;
+    } else if (epi == PARROT_EPI_GELU) {
+        v = gelu_erf(v);
+    } else if (epi == PARROT_EPI_SWIGLU) {
+        v = rbf(silu(v)) * rbf(acc2);
+    }
+    return f2bf(v);
+}
 __device__ __forceinline__ bf16_t apply_epilogue(int epi, float acc, float acc2, const bf16_t* bias,
                                                  const bf16_t* residual, int col) {
     return apply_epilogue_v(epi, acc, acc2, bias, epi == PARROT_EPI_RESIDUAL ? bf2f(residual[col]) : 0.f, col);
 }
 
-// ---------------------------------------------------------------- chained launches ("chains")
-// A chained kernel is launched while its predecessor (on the other of two streams) is still running.  It requests
-// everything that does not depend on the predecessor (weights, norm parameters, KV rows), then waits IN the kernel for
-// the predecessor's arrival counters, and only then reads the activations.  Hand-off data is written with write-through
-// agent-scope stores and read with agent-scope loads; a workgroup adds 1 to its shard of the counters after its stores
-// have drained.  Deadlock freedom is a launch-shape property checked on the host: both grids of an adjacent pair are
-// co-resident (<= 256 workgroups, each <= half a CU), so the predecessor never waits for a slot held by a spinning
-// successor.  The wait is bounded (20 ms) all the same: a timeout sets *err and lets the grid drain.
-struct ChainArgs {
-    const uint32_t* wait;  // predecessor's counters (nullptr: nothing to wait for)
-    uint32_t wait_target;  // predecessor's workgroup count
-    uint32_t* signal;      // this launch's counters (nullptr: nobody waits for it in-kernel)
-    uint32_t* err;         // timeout word
-    unsigned long long* dbg;  // diagnostic: 4 x 100 MHz stamps of workgroup 0 (start, waited, computed, signalled) or nullptr
-};
-__device__ __forceinline__ void chain_stamp(const ChainArgs& ca, int i) {
-    if (ca.dbg != nullptr && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0)
-        ca.dbg[i] = __builtin_amdgcn_s_memrealtime();
-}
-constexpr int kChainShards = 16;        // counters per launch, one 128-B line each
-constexpr int kChainShardStride = 32;   // dwords
-
+// ---------------------------------------------------------------- agent-scope accessors
+// For data that another workgroup of the same launch produces or consumes (attention partials, the persistent step):
+// write-through stores / L2-bypassing loads; pair with s_waitcnt vmcnt(0) + barrier + one relaxed agent atomic.
 __device__ __forceinline__ uint64_t ld_agent64(const void* p) {
     return __hip_atomic_load(reinterpret_cast<const uint64_t*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 __device__ __forceinline__ uint32_t ld_agent32(const void* p) {
     return __hip_atomic_load(reinterpret_cast<const uint32_t*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ bf16_t ld_agent16(const bf16_t* p) {
-    return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ void st_agent16(bf16_t* p, bf16_t v) {
-    __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ uint4 ld_agent128(const void* p) {  // two 8-byte agent-scope loads
-    const uint64_t a = ld_agent64(p), b = ld_agent64(reinterpret_cast<const uint64_t*>(p) + 1);
-    return make_uint4((uint32_t)a, (uint32_t)(a >> 32), (uint32_t)b, (uint32_t)(b >> 32));
-}
-
-// whole workgroup: returns once the predecessor has fully arrived (or the wait timed out / an earlier one did)
-__device__ __forceinline__ void chain_wait(const ChainArgs& ca) {
-    if (ca.wait == nullptr) return;
-    if (threadIdx.x < 64) {
-        const int lane = threadIdx.x;
-        const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-        while (true) {
-            uint32_t v = 0;
-            if (lane < kChainShards) v = ld_agent32(ca.wait + lane * kChainShardStride);
-            if (lane == kChainShards) v = ld_agent32(ca.err) ? 0x40000000u : 0u;  // an earlier timeout: do not wait again
-#pragma unroll
-            for (int off = 16; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);  // lanes 0..31 hold everything
-            v = __builtin_amdgcn_readfirstlane(v);
-            if (v >= ca.wait_target) break;
-            if (__builtin_amdgcn_s_memrealtime() - t0 > 2000000ull) {  // 20 ms at 100 MHz
-                if (lane == 0) __hip_atomic_store(ca.err, 0x80000000u | ca.wait_target, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                break;
-            }
-            __builtin_amdgcn_s_sleep(2);
-        }
-    }
-    __syncthreads();
-}
-// one thread, after every hand-off store of the workgroup has drained (s_waitcnt vmcnt(0) in the storing waves, barrier)
-__device__ __forceinline__ void chain_signal(const ChainArgs& ca, int wg_linear) {
-    if (ca.signal != nullptr)
-        __hip_atomic_fetch_add(ca.signal + (wg_linear % kChainShards) * kChainShardStride, 1u, __ATOMIC_RELAXED,
-                               __HIP_MEMORY_SCOPE_AGENT);
 }
 
 }  // namespace parrot

@@ -116,7 +116,7 @@ template <int M, bool DUAL, int RU, int MAXW>
 __global__ void __launch_bounds__(MAXW * 64)
 w4_gemv_kernel(const uint4* __restrict__ W, const uint4* __restrict__ W2, const bf16_t* __restrict__ x, int ldx,
                const bf16_t* __restrict__ bias, const bf16_t* residual, int ldr, bf16_t* out, int ldo, int N, int K,
-               int wps, int epi, int iters, NormArgs na, W4Plan plan, unsigned long long* dbg, int knob) {
+               int wps, int epi, int iters, NormArgs na, W4Plan plan, unsigned long long* dbg) {
     constexpr int NW = DUAL ? 2 : 1;
     extern __shared__ __attribute__((aligned(16))) unsigned char w4_smem[];  // normalised activations [M][K] bf16 (norm only)
     __shared__ float red[2][MAXW][RU * M * NW];  // double-buffered over the batches: one barrier per batch
@@ -184,6 +184,9 @@ w4_gemv_kernel(const uint4* __restrict__ W, const uint4* __restrict__ W2, const 
     // CU) have returned at HBM speed, and everything behind them in program order - the fused norm above all - waits
     // too.  About 3 KB per wave in flight already covers the HBM latency-bandwidth product, so PRIME rows are requested
     // up front and row u + PRIME (of this batch, or of the next one) is requested right before row u is consumed.
+    // (Measured alternatives: PRIME 5 - no gain; requesting the whole batch at once for small launches behind a run-time
+    //  flag - 6 % SLOWER overall, because loads under a run-time condition defeat the compiler's static vmcnt
+    //  bookkeeping and every wait becomes vmcnt(0).  Keep every load of this kernel unconditional.)
     constexpr int PRIME = (RU * NW >= 8) ? 3 : 2;
     static_assert(PRIME <= RU, "rolling window longer than a batch");
     // first row of this wave in batch T; batches past the matrix are clamped to the last row (loaded, never stored)
@@ -200,12 +203,6 @@ w4_gemv_kernel(const uint4* __restrict__ W, const uint4* __restrict__ W2, const 
             w[1][U] = load_nt16(rec2_ + sl.w_off16 + lslice);                                         \
             mt[1][U] = load_nt4(reinterpret_cast<const uint32_t*>(rec2_ + sl.meta_off16) + gl);       \
         }                                                                                             \
-    }
-    if (na.kind != 0) {  // EXPERIMENT knob: what to do between the activation requests and the first weight requests
-        if (knob == 1) __builtin_amdgcn_s_sleep(20);
-        if (knob == 2) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (knob == 3) __syncthreads();
-        if (knob == 4) __builtin_amdgcn_s_sleep(60);
     }
 #pragma unroll
     for (int u = 0; u < PRIME; ++u) W4_ISSUE_ROW(0, u)
@@ -282,8 +279,17 @@ w4_gemv_kernel(const uint4* __restrict__ W, const uint4* __restrict__ W2, const 
     }
     w4_stamp(dbg, 1);
 
+    // bias / residual elements of the epilogue threads: requested at the START of a batch (every thread, clamped, always:
+    // a load behind a condition would cost the compiler its static vmcnt bookkeeping), so that the kernel's tail does not
+    // end with "load residual -> wait a full memory latency -> add -> store"
+    const bf16_t* res_p = residual != nullptr ? residual : reinterpret_cast<const bf16_t*>(W);
+    const bf16_t* bias_p = bias != nullptr ? bias : reinterpret_cast<const bf16_t*>(W);
+    const int e_m = threadIdx.x % M, e_ur = threadIdx.x / M;
     for (int t = 0; t < iters; ++t) {
         float(*rd)[RU * M * NW] = red[t & 1];
+        const int e_col = min(((int)blockIdx.x + t * (int)gridDim.x) * R + e_ur, N - 1);
+        const bf16_t e_res = res_p[residual != nullptr ? (int64_t)e_m * ldr + e_col : 0];
+        const bf16_t e_bias = bias_p[bias != nullptr ? e_col : 0];
 #pragma unroll
         for (int u = 0; u < RU; ++u) {
             // request row u + PRIME: of this batch, or - across the batch boundary - of the next one
@@ -326,8 +332,7 @@ w4_gemv_kernel(const uint4* __restrict__ W, const uint4* __restrict__ W2, const 
                     a0 += rd[c * wps + jj][(u * M + m) * NW];
                     if (DUAL) a1 += rd[c * wps + jj][(u * M + m) * NW + 1];
                 }
-                out[(int64_t)m * ldo + col] =
-                    apply_epilogue(epi, a0, a1, bias, residual ? residual + (int64_t)m * ldr : nullptr, col);
+                out[(int64_t)m * ldo + col] = apply_epilogue_vals(epi, a0, a1, bias != nullptr, bf2f(e_bias), bf2f(e_res));
             }
         }
     }
@@ -344,16 +349,11 @@ w4_gemv_kernel(const uint4* __restrict__ W, const uint4* __restrict__ W2, const 
 // HBM stream runs under the arithmetic, and the activation / norm prologue is paid once per workgroup under the first loads.
 //   workgroup b owns row groups b, b + G, b + 2G, ...; its t-th group goes to wave column j = t % wps in batch t / wps;
 //   the nslabs waves of a column split K; per batch one barrier: slab partials -> LDS (double-buffered) -> epilogue.
-//
-// CHAIN = true is the chained-launch form (parrot_common.h, "chained launches"): the norm parameters and the first two
-// batches of weights are requested, THEN the workgroup waits for the previous launch of the chain, and only then reads
-// the activations (agent-scope loads) - so the launch ramp, the weight latency and the previous kernel's tail overlap.
-// Outputs are write-through stores; wave 0 (the only storing wave) signals after they have drained.
-template <bool DUAL, int RU, int MAXW, bool CHAIN>
+template <bool DUAL, int RU, int MAXW>
 __global__ void __launch_bounds__(MAXW * 64)
-w4_stream_kernel(const uint4* __restrict__ W, const uint4* __restrict__ W2, const bf16_t* x,
+w4_stream_kernel(const uint4* __restrict__ W, const uint4* __restrict__ W2, const bf16_t* __restrict__ x,
                  const bf16_t* __restrict__ bias, const bf16_t* residual, bf16_t* out, int N, int K, int wps, int epi,
-                 NormArgs na, W4Plan plan, ChainArgs ca) {
+                 NormArgs na, W4Plan plan) {
     constexpr int NW = DUAL ? 2 : 1;
     extern __shared__ __attribute__((aligned(16))) unsigned char w4_smem[];  // normalised activations [K] bf16 (norm only)
     __shared__ float red[2][MAXW][RU * NW];
@@ -381,14 +381,12 @@ w4_stream_kernel(const uint4* __restrict__ W, const uint4* __restrict__ W2, cons
     constexpr int kMaxChunkIt = 4;
     uint4 cx[kMaxChunkIt], cw[kMaxChunkIt], cb[kMaxChunkIt];
     if (na.kind == 0) {
-        if (!CHAIN) {
-            const uint4* xp = reinterpret_cast<const uint4*>(x + (int64_t)gslice * 32);
+        const uint4* xp = reinterpret_cast<const uint4*>(x + (int64_t)gslice * 32);
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                uint4 v = xp[q];
-                if (!active) v = make_uint4(0, 0, 0, 0);
-                xr[4 * q + 0] = v.x; xr[4 * q + 1] = v.y; xr[4 * q + 2] = v.z; xr[4 * q + 3] = v.w;
-            }
+        for (int q = 0; q < 4; ++q) {
+            uint4 v = xp[q];
+            if (!active) v = make_uint4(0, 0, 0, 0);
+            xr[4 * q + 0] = v.x; xr[4 * q + 1] = v.y; xr[4 * q + 2] = v.z; xr[4 * q + 3] = v.w;
         }
     } else {
 #pragma unroll
@@ -398,10 +396,8 @@ w4_stream_kernel(const uint4* __restrict__ W, const uint4* __restrict__ W2, cons
             cw[it] = reinterpret_cast<const uint4*>(na.weight)[cc];
             cb[it] = make_uint4(0, 0, 0, 0);
             if (na.kind == 2 && na.bias != nullptr) cb[it] = reinterpret_cast<const uint4*>(na.bias)[cc];
-            if (!CHAIN) {
-                cx[it] = reinterpret_cast<const uint4*>(x)[cc];
-                if (c >= chunks) cx[it] = make_uint4(0, 0, 0, 0);
-            }
+            cx[it] = reinterpret_cast<const uint4*>(x)[cc];
+            if (c >= chunks) cx[it] = make_uint4(0, 0, 0, 0);
         }
     }
 
@@ -426,28 +422,6 @@ w4_stream_kernel(const uint4* __restrict__ W, const uint4* __restrict__ W2, cons
     }
     if (batches > 0) W4S_LOAD(0, 0)
     if (batches > 1) W4S_LOAD(1, 1)
-
-    if (CHAIN) {
-        chain_stamp(ca, 0);
-        chain_wait(ca);
-        chain_stamp(ca, 1);
-        if (na.kind == 0) {
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                uint4 v = ld_agent128(x + (int64_t)gslice * 32 + q * 8);
-                if (!active) v = make_uint4(0, 0, 0, 0);
-                xr[4 * q + 0] = v.x; xr[4 * q + 1] = v.y; xr[4 * q + 2] = v.z; xr[4 * q + 3] = v.w;
-            }
-        } else {
-#pragma unroll
-            for (int it = 0; it < kMaxChunkIt; ++it) {
-                const int c = threadIdx.x + it * nthreads;
-                const int cc = c < chunks ? c : chunks - 1;
-                cx[it] = ld_agent128(x + (int64_t)cc * 8);
-                if (c >= chunks) cx[it] = make_uint4(0, 0, 0, 0);
-            }
-        }
-    }
 
     if (na.kind != 0) {  // fused RMSNorm / LayerNorm, once per workgroup, through LDS
         uint4* xn = reinterpret_cast<uint4*>(w4_smem);
@@ -525,12 +499,7 @@ w4_stream_kernel(const uint4* __restrict__ W, const uint4* __restrict__ W2, cons
                     a0 += red[(BI) & 1][c * wps + jj][u * NW];                                                     \
                     if (DUAL) a1 += red[(BI) & 1][c * wps + jj][u * NW + 1];                                       \
                 }                                                                                                  \
-                if (CHAIN) {                                                                                       \
-                    const float res_ = epi == PARROT_EPI_RESIDUAL ? bf2f(ld_agent16(residual + col)) : 0.f;       \
-                    st_agent16(out + col, apply_epilogue_v(epi, a0, a1, bias, res_, col));                         \
-                } else {                                                                                           \
-                    out[col] = apply_epilogue(epi, a0, a1, bias, residual, col);                                   \
-                }                                                                                                  \
+                out[col] = apply_epilogue(epi, a0, a1, bias, residual, col);                                       \
             }                                                                                                      \
         }                                                                                                          \
     }
@@ -540,17 +509,10 @@ w4_stream_kernel(const uint4* __restrict__ W, const uint4* __restrict__ W2, cons
     }
 #undef W4S_STEP
 #undef W4S_LOAD
-    if (CHAIN && threadIdx.x < 64) {  // every output store of this workgroup was issued by wave 0
-        chain_stamp(ca, 2);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        if (threadIdx.x == 0) chain_signal(ca, blockIdx.x);
-        chain_stamp(ca, 3);
-    }
 }
 
 static int g_stream_wgs_per_cu_x2 = 0;  // tuning hook: workgroups per 128 CUs ... (0 = heuristic)
 
-static int g_w4_knob = 0;  // experiment hook
 static int g_resident_override = 0;  // tuning hook: workgroups per launch before a workgroup walks several batches
 static int g_wps_override = 0;  // tuning hook (tools/microbench.py): row groups per workgroup, 0 = heuristic
 
@@ -597,7 +559,7 @@ static int w4_gemv_launch_v(const void* packed, const void* packed2, const void*
     const dim3 grid((batches + iters - 1) / iters), block(nthreads);
     return launch(DUAL ? K_W4_GEMV_DUAL : K_W4_GEMV, w4_gemv_kernel<M, DUAL, RU, MAXW>, grid, block, lds, st,
                   (const uint4*)packed, (const uint4*)packed2, (const bf16_t*)x, ldx, (const bf16_t*)bias,
-                  (const bf16_t*)residual, ldr, (bf16_t*)out, ldo, N, K, wps, epi, iters, na, plan, g_w4_dbg_host, g_w4_knob);
+                  (const bf16_t*)residual, ldr, (bf16_t*)out, ldo, N, K, wps, epi, iters, na, plan, g_w4_dbg_host);
 }
 
 static int g_use_stream = 0;  // the pipelined kernel measured no faster than the burst kernel (tools/microbench.py); kept selectable
@@ -618,37 +580,9 @@ static int w4_stream_launch(const void* packed, const void* packed2, const void*
         PARROT_UNSUPPORTED((K >> 3) <= 4 * nthreads, "w4_gemv: fused norm needs K <= %d with this workgroup shape", 32 * nthreads);
         lds = (size_t)K * 2;
     }
-    return launch(DUAL ? K_W4_GEMV_DUAL : K_W4_GEMV, w4_stream_kernel<DUAL, RU, MAXW, false>, dim3(G), dim3(nthreads), lds, st,
+    return launch(DUAL ? K_W4_GEMV_DUAL : K_W4_GEMV, w4_stream_kernel<DUAL, RU, MAXW>, dim3(G), dim3(nthreads), lds, st,
                   (const uint4*)packed, (const uint4*)packed2, (const bf16_t*)x, (const bf16_t*)bias, (const bf16_t*)residual,
-                  (bf16_t*)out, N, K, wps, epi, na, plan, ChainArgs{nullptr, 0u, nullptr, nullptr, nullptr});
-}
-
-// Chained form.  Launch shape rule (co-residency of adjacent launches, parrot_common.h): at most 256 workgroups, each at
-// most half a CU: WAVES waves x the build's VGPR bound (8 -> 256, 16 -> 128) <= 1024 wave-VGPRs, LDS <= 64 KB.
-constexpr int kChainMaxWgs = 256;
-template <bool DUAL, int RU, int MAXW>
-static int w4_chain_launch(const void* packed, const void* packed2, const void* x, const void* bias, const void* residual,
-                           void* out, int N, int K, int epi, const NormArgs& na, const W4Plan& plan, parrot_chain_t* ch,
-                           hipStream_t st) {
-    const int max_waves = MAXW == 8 ? 4 : 8;
-    int wps = max_waves / plan.nslabs;
-    if (wps > 2) wps = 2;
-    PARROT_UNSUPPORTED(wps >= 1, "w4_gemv_chained: K = %d needs %d waves per row group", K, plan.nslabs);
-    const int ngroups = (N + RU - 1) / RU;
-    int G = kChainMaxWgs;
-    if (G * wps > ngroups) G = (ngroups + wps - 1) / wps;
-    const int nthreads = 64 * plan.nslabs * wps;
-    size_t lds = 0;
-    if (na.kind != 0) {
-        PARROT_UNSUPPORTED((K >> 3) <= 4 * nthreads, "w4_gemv_chained: fused norm needs K <= %d with this workgroup shape", 32 * nthreads);
-        lds = (size_t)K * 2;
-        PARROT_UNSUPPORTED(lds <= 60 * 1024, "w4_gemv_chained: fused norm needs %zu B of LDS", lds);
-    }
-    const ChainArgs ca{ch->wait, ch->wait_target, ch->signal, ch->err, (unsigned long long*)ch->stamps};
-    ch->workgroups = (uint32_t)G;
-    return launch(DUAL ? K_W4_GEMV_DUAL : K_W4_GEMV, w4_stream_kernel<DUAL, RU, MAXW, true>, dim3(G), dim3(nthreads), lds, st,
-                  (const uint4*)packed, (const uint4*)packed2, (const bf16_t*)x, (const bf16_t*)bias, (const bf16_t*)residual,
-                  (bf16_t*)out, N, K, wps, epi, na, plan, ca);
+                  (bf16_t*)out, N, K, wps, epi, na, plan);
 }
 
 template <int M>
@@ -695,11 +629,6 @@ int parrot_tune_w4_stream(int use_stream, int wgs_per_128_cus) {  // diagnostic 
     return PARROT_OK;
 }
 
-int parrot_tune_w4_knob(int knob) {
-    g_w4_knob = knob;
-    return PARROT_OK;
-}
-
 int parrot_tune_w4_resident(int workgroups) {  // 0 = derive from the workgroup shape
     g_resident_override = workgroups > 0 ? workgroups : 0;
     return PARROT_OK;
@@ -730,44 +659,6 @@ int parrot_w4_repack(void* quant_weight_ref, void* scales, void* zeros, int N, i
     PARROT_UNSUPPORTED(blocks < (1ll << 31), "w4_repack: matrix too large");
     return launch(K_W4_REPACK, w4_repack_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
                   (uint8_t*)quant_weight_ref, (bf16_t*)scales, (bf16_t*)zeros, (uint4*)packed, N, direction, plan);
-}
-
-int parrot_w4_gemv_chained_supported(int N, int K, int group, int with_norm) {
-    W4Plan plan;
-    const int rc = w4_make_plan(N, K, group, &plan);
-    if (rc != PARROT_OK) return rc;
-    const int max_waves = plan.nslabs <= 4 ? 4 : 8;
-    int wps = max_waves / plan.nslabs;
-    if (wps > 2) wps = 2;
-    PARROT_UNSUPPORTED(wps >= 1, "w4_gemv_chained: K = %d needs %d waves per row group (at most 8 can be chained)", K, plan.nslabs);
-    if (with_norm) {
-        const int nthreads = 64 * plan.nslabs * wps;
-        PARROT_UNSUPPORTED((K >> 3) <= 4 * nthreads && (size_t)K * 2 <= 60 * 1024, "w4_gemv_chained: fused norm over K = %d does not fit", K);
-    }
-    return PARROT_OK;
-}
-
-int parrot_w4_gemv_chained(const void* packed, const void* packed2, const void* x, const void* bias, const void* residual,
-                           void* out, int N, int K, int group, int epilogue, const parrot_norm_t* norm,
-                           parrot_chain_t* chain, void* stream) {
-    int rc = check_linear_args("w4_gemv_chained", packed, packed2, x, K, 1, residual, N, out, N, N, K, epilogue);
-    if (rc != PARROT_OK) return rc;
-    PARROT_REQUIRE(chain != nullptr && chain->err != nullptr, "w4_gemv_chained: chain descriptor / error word missing");
-    PARROT_REQUIRE(chain->wait == nullptr || chain->wait_target >= 1, "w4_gemv_chained: wait without a target");
-    PARROT_UNSUPPORTED(!(epilogue == PARROT_EPI_SWIGLU && bias), "w4_gemv_chained: SWIGLU epilogue takes no bias");
-    W4Plan plan;
-    rc = w4_make_plan(N, K, group, &plan);
-    if (rc != PARROT_OK) return rc;
-    NormArgs na;
-    rc = make_norm_args(norm, K, &na);
-    if (rc != PARROT_OK) return rc;
-    hipStream_t st = (hipStream_t)stream;
-    const bool dual = epilogue == PARROT_EPI_SWIGLU;
-    if (plan.nslabs <= 4)
-        return dual ? w4_chain_launch<true, 4, 8>(packed, packed2, x, bias, residual, out, N, K, epilogue, na, plan, chain, st)
-                    : w4_chain_launch<false, 8, 8>(packed, packed2, x, bias, residual, out, N, K, epilogue, na, plan, chain, st);
-    return dual ? w4_chain_launch<true, 2, 16>(packed, packed2, x, bias, residual, out, N, K, epilogue, na, plan, chain, st)
-                : w4_chain_launch<false, 4, 16>(packed, packed2, x, bias, residual, out, N, K, epilogue, na, plan, chain, st);
 }
 
 int parrot_w4_gemv(const void* packed, const void* packed2, const void* x, int ldx, int M, const void* bias,

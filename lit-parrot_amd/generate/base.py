@@ -17,7 +17,6 @@ multinomial, :139-144) run as torch ops on the device, so the same torch seed dr
 The prompt is prefilled in one multi-row pass (same kernels, M = T rows) that computes only the last row of lm_head
 (the reference computes all T rows and discards T-1 of them, :135-136).
 """
-import os
 from typing import Dict, Optional, Tuple
 
 import torch
@@ -31,7 +30,7 @@ class DecodeSession:
     """Static buffers + captured graph of the single-token step for one (model, max_seq_length, greedy) choice."""
 
     def __init__(self, model: GPT, max_seq_length: int, max_tokens: int, greedy: bool, use_graph: bool = True,
-                 persistent: Optional[bool] = None, chained: Optional[bool] = None) -> None:
+                 persistent: Optional[bool] = None) -> None:
         self.model, self.S, self.greedy = model, max_seq_length, greedy
         dev = model.transformer.wte.weight.device
         if dev.type != "cuda":
@@ -56,20 +55,13 @@ class DecodeSession:
         if persistent and PersistentStep.supported(model) is None:
             self.pk = PersistentStep(model, self.tokens, self.pos, self.caches, max_seq_length, greedy)
 
-        # chained launches (two streams + in-kernel arrival counters) when every Linear has a chained form
-        self.chain: Optional[ops.Chain] = None
-        if chained is None:
-            chained = CHAINED_DEFAULT
-        if chained and self.pk is None and use_graph and chain_supported(model) is None:
-            self.chain = ops.Chain(dev, 5 * model.config.n_layer + 1)
 
     # one decode step = the launch sequence that gets captured
     def _step(self) -> None:
         if self.pk is not None:
             self.pk.step()  # embedding .. lm_head (.. arg-max + advance when greedy) in one launch
             return
-        logits = self.model.run_rows(self.ws, self.tokens, self.pos, self.pos, self.S, self.caches, self.model.rope_cache,
-                                     chain=self.chain)
+        logits = self.model.run_rows(self.ws, self.tokens, self.pos, self.pos, self.S, self.caches, self.model.rope_cache)
         if self.greedy:
             ops.argmax_advance(logits, self.tokens, self.pos)
 
@@ -113,30 +105,6 @@ class DecodeSession:
         return self.pk.logits[0] if self.pk is not None else self.ws.logits[0]
 
 
-def chain_supported(model: GPT) -> Optional[str]:
-    """None if the single-token step of ``model`` can run as chained launches, else the reason."""
-    from .. import _hip
-    from ..quantize.gptq import ColBlockQuantizedLinear
-
-    c = model.config
-    lib = _hip.load()
-    fused_norm_inputs = {id(model.lm_head)}
-    for block in model.transformer.h:
-        fused_norm_inputs.add(id(block.attn.attn))
-        fused_norm_inputs.add(id(block.mlp.fc_1 if hasattr(block.mlp, "fc_1") else block.mlp.fc))
-    linears = [m for m in model.modules() if isinstance(m, torch.nn.Linear) or hasattr(m, "hip_linear")]
-    for m in linears:
-        if not isinstance(m, ColBlockQuantizedLinear):
-            return "not every Linear is an int4 ColBlockQuantizedLinear"
-        if lib.parrot_w4_gemv_chained_supported(m.out_features, m.in_features, m.tile_cols, int(id(m) in fused_norm_inputs)) != 0:
-            return _hip.last_error()
-    chunks = (c.q_per_kv + 3) // 4 if c.q_per_kv > 2 else 1
-    if c.q_per_kv > ops.FUSED_ATTN_MAX_Q_PER_KV or c.n_query_groups * chunks > ops.CHAIN_MAX_WGS:
-        return "query group count"
-    return None
-
-
-CHAINED_DEFAULT = os.environ.get("PARROT_CHAINED", "0") != "0"
 PERSISTENT_DEFAULT = False  # experimental: correct, but its per-op software barrier is still slower than kernel boundaries (DESIGN.md §9)
 
 
@@ -205,6 +173,4 @@ def generate(
             logits = sess.step()
     else:
         i = n_new
-    if sess.chain is not None:
-        sess.chain.check()  # a chained step whose in-kernel wait timed out produced garbage: fail loudly
     return sess.tokens[: T + i].to(dtype).clone()

@@ -137,7 +137,7 @@ def _linear(mod: nn.Module, x: torch.Tensor, out: torch.Tensor, *, epilogue: int
     """Run one Linear-shaped module on rows with a fused epilogue — and optionally the norm module in front of it
     fused as a prologue — whatever class ``quantization()`` installed."""
     norm = _fused_norm(norm)
-    if _ACTIVE_PREFETCHER is not None and x.shape[0] == 1 and ops.ACTIVE_CHAIN is None:
+    if _ACTIVE_PREFETCHER is not None and x.shape[0] == 1:
         _ACTIVE_PREFETCHER.before(mod)
     if hasattr(mod, "hip_linear"):
         return mod.hip_linear(x, out, epilogue=epilogue, residual=residual, partner=partner, norm=norm)
@@ -230,8 +230,7 @@ class GPT(nn.Module):
 
     # ------------------------------------------------------------------------------------------ execution
     def run_rows(self, ws: Workspace, tokens: torch.Tensor, tok_pos: Optional[torch.Tensor], pos: torch.Tensor,
-                 S: int, caches: List[KVCache], rope: RoPECache, *, rope_local: bool = False,
-                 chain: Optional[ops.Chain] = None) -> torch.Tensor:
+                 S: int, caches: List[KVCache], rope: RoPECache, *, rope_local: bool = False) -> torch.Tensor:
         """Embed ``ws.M`` tokens (``tokens[tok_pos + m]``), run every block, final norm and lm_head.
 
         ``pos`` (device int32[1]) is the position of row 0; ``caches[i]`` are (n_groups, S, hs) views.  Returns
@@ -241,18 +240,6 @@ class GPT(nn.Module):
         M = ws.M
         ops.embedding(self.transformer.wte.weight.data, tokens, tok_pos, M, ws.x)
         nsplit = ops.attn_nsplit(self.config.n_query_groups, S, self.config.q_per_kv, M)
-        if chain is not None:  # single-token step as chained launches on two streams (ops.Chain)
-            if M != 1 or rope_local:
-                raise ParrotHipError("chained step: one token at a time")
-            nsplit = ops.attn_nsplit_chained(self.config.n_query_groups, S, self.config.q_per_kv)
-            chain.begin()
-            try:
-                for block, (kc, vc) in zip(self.transformer.h, caches):
-                    block.run_rows(ws, pos, S, kc, vc, rope, nsplit, rope_local)
-                logits = _linear(self.lm_head, ws.x, ws.logits, norm=self.transformer.ln_f)
-            finally:
-                chain.end()
-            return logits
         use_pf = M == 1 and WEIGHT_PREFETCH != "0" and not self.config.parallel_residual
         if use_pf and getattr(self, "_prefetcher", None) is None:
             lim = int(WEIGHT_PREFETCH) * (1 << 20) if WEIGHT_PREFETCH.isdigit() and int(WEIGHT_PREFETCH) > 1 else None
@@ -331,7 +318,7 @@ class Block(nn.Module):
             # stream next to [QKV -> attention -> proj]: inside the captured graph they become parallel nodes and the
             # weight stream of one covers the dispatch / latency gaps of the other.
             mlp_norm = self.norm_1 if c.shared_attention_norm else self.norm_2
-            if PARALLEL_BRANCHES and ws.M == 1 and ops.ACTIVE_CHAIN is None:
+            if PARALLEL_BRANCHES and ws.M == 1:
                 if ws.side_stream is None:
                     ws.side_stream = torch.cuda.Stream(device=ws.x.device)
                 main = torch.cuda.current_stream(ws.x.device)

@@ -37,7 +37,6 @@ RMSNORM_RSQRT_MODE = 0
 
 
 def rmsnorm(x: torch.Tensor, weight: torch.Tensor, eps: float, out: torch.Tensor) -> torch.Tensor:
-    _not_chained("rmsnorm")
     _rows(x, "rmsnorm"), _rows(out, "rmsnorm")
     M, d = x.shape
     check(_hip.load().parrot_rmsnorm(ptr(x), x.stride(0), ptr(_opt_vec(weight, d, "rmsnorm weight")), ptr(out),
@@ -47,7 +46,6 @@ def rmsnorm(x: torch.Tensor, weight: torch.Tensor, eps: float, out: torch.Tensor
 
 def layernorm(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor], eps: float,
               out: torch.Tensor) -> torch.Tensor:
-    _not_chained("layernorm")
     _rows(x, "layernorm"), _rows(out, "layernorm")
     M, d = x.shape
     check(_hip.load().parrot_layernorm(ptr(x), x.stride(0), ptr(_opt_vec(weight, d, "layernorm weight")),
@@ -89,7 +87,6 @@ def _norm_arg(norm: Optional[Norm], K: int):
 # ------------------------------------------------------------------------------------------------ linears
 def bf16_linear(weight: torch.Tensor, x: torch.Tensor, out: torch.Tensor, *, bias=None, epilogue=EPI_NONE,
                 residual=None, weight2=None, norm: Optional[Norm] = None) -> torch.Tensor:
-    _not_chained("bf16_linear")
     _rows(x, "bf16_linear"), _rows(out, "bf16_linear")
     x, norm = _prenorm(x, norm)
     N, K = weight.shape
@@ -125,79 +122,6 @@ def w4_repack(quant_weight: torch.Tensor, scales: torch.Tensor, zeros: torch.Ten
                                        stream()), "parrot_w4_repack")
 
 
-class Chain:
-    """Sequencer of the chained single-token step (include/parrot_hip.h, "chained launches").
-
-    Between ``begin()`` and ``end()`` every int4 GEMV and fused-attention launch of a single row goes alternately to
-    two streams and waits in-kernel for its predecessor's arrival counters instead of for a kernel boundary.  The
-    sequence is meant to be captured in a hipGraph (the two streams become two parallel node chains)."""
-
-    def __init__(self, device, max_launches: int) -> None:
-        self.device = device
-        self.counters = torch.zeros((max_launches, _hip.CHAIN_COUNTER_WORDS), dtype=torch.int32, device=device)
-        self.err = torch.zeros((1,), dtype=torch.int32, device=device)
-        self.side = torch.cuda.Stream(device=device)
-        self.desc = _hip.ParrotChain()
-        self.i = 0
-        self.prev_wgs = 0
-        self.main: Optional[torch.cuda.Stream] = None
-        self.stamps: Optional[torch.Tensor] = None  # enable_stamps(): [launch][4] device clock values
-
-    def enable_stamps(self) -> torch.Tensor:
-        self.stamps = torch.zeros((self.counters.shape[0], 4), dtype=torch.int64, device=self.device)
-        return self.stamps
-
-    def begin(self) -> None:
-        global ACTIVE_CHAIN
-        if ACTIVE_CHAIN is not None:
-            raise ParrotHipError("a chained step is already being enqueued")
-        self.main = torch.cuda.current_stream(self.device)
-        self.counters.zero_()
-        self.i, self.prev_wgs = 0, 0
-        ACTIVE_CHAIN = self
-
-    def next(self):
-        """(descriptor, raw stream) of the next launch; call ``done()`` after it has been enqueued."""
-        if self.i >= self.counters.shape[0]:
-            raise ParrotHipError("chained step: more launches than counters")
-        if self.i == 1:
-            self.side.wait_stream(self.main)  # fork: everything before the first launch is visible to both chains
-        d = self.desc
-        d.wait = self.counters[self.i - 1].data_ptr() if self.i > 0 else None
-        d.wait_target = self.prev_wgs
-        d.signal = self.counters[self.i].data_ptr()
-        d.err = self.err.data_ptr()
-        d.workgroups = 0
-        d.stamps = self.stamps[self.i].data_ptr() if self.stamps is not None else None
-        st = self.main if self.i % 2 == 0 else self.side
-        return d, st.cuda_stream
-
-    def done(self) -> None:
-        self.prev_wgs = int(self.desc.workgroups)
-        self.i += 1
-
-    def end(self) -> None:
-        global ACTIVE_CHAIN
-        ACTIVE_CHAIN = None
-        if self.i > 1:
-            self.main.wait_stream(self.side)  # join: the step's results are visible to what follows on the main stream
-
-    def check(self) -> None:
-        """Host-side check of the timeout word (syncs)."""
-        e = int(self.err.item())
-        if e:
-            self.err.zero_()
-            raise ParrotHipError(f"chained step: an in-kernel wait timed out (error word {e & 0xffffffff:#x})")
-
-
-ACTIVE_CHAIN: Optional[Chain] = None
-
-
-def _not_chained(op: str) -> None:
-    if ACTIVE_CHAIN is not None:
-        raise ParrotHipError(f"{op}: no chained form; the chained step takes int4 GEMVs and the fused attention only")
-
-
 def w4_linear(packed: torch.Tensor, N: int, K: int, group: int, x: torch.Tensor, out: torch.Tensor, *, bias=None,
               epilogue=EPI_NONE, residual=None, packed2=None, norm: Optional[Norm] = None) -> torch.Tensor:
     _rows(x, "w4_linear"), _rows(out, "w4_linear")
@@ -206,15 +130,6 @@ def w4_linear(packed: torch.Tensor, N: int, K: int, group: int, x: torch.Tensor,
     if x.shape[1] != K or out.shape[1] != N:
         raise ParrotHipError(f"w4_linear: x {tuple(x.shape)} / out {tuple(out.shape)} do not match N={N} K={K}")
     lib = _hip.load()
-    if ACTIVE_CHAIN is not None:
-        if M != 1 or not x.is_contiguous():
-            raise ParrotHipError("chained step: single contiguous rows only")
-        d, st = ACTIVE_CHAIN.next()
-        check(lib.parrot_w4_gemv_chained(ptr(packed), ptr(packed2), ptr(x), ptr(_opt_vec(bias, N, "bias")), ptr(residual),
-                                         ptr(out), N, K, group, epilogue, _norm_arg(norm, K), C.byref(d), st),
-              "parrot_w4_gemv_chained")
-        ACTIVE_CHAIN.done()
-        return out
     args = (ptr(packed), ptr(packed2), ptr(x), x.stride(0), M, ptr(_opt_vec(bias, N, "bias")), ptr(residual),
             residual.stride(0) if residual is not None else 0, ptr(out), out.stride(0), N, K, group, epilogue,
             _norm_arg(norm, K))
@@ -246,7 +161,6 @@ class W8Act:
 
 
 def w8_prep_act(x: torch.Tensor, threshold: float, act: W8Act, norm: Optional[Norm] = None) -> W8Act:
-    _not_chained("w8_prep_act")
     _rows(x, "w8_prep_act")
     M, K = x.shape
     assert (M, K) == (act.M, act.K)
@@ -269,7 +183,6 @@ def w8_linear(CB: torch.Tensor, SCB: torch.Tensor, N: int, K: int, act: W8Act, o
 def rope_kvappend(qkv: torch.Tensor, cos: torch.Tensor, sin: torch.Tensor, n_elem: int, pos: torch.Tensor,
                   n_groups: int, q_per_kv: int, hs: int, S: int, q_out: torch.Tensor, k_cache: torch.Tensor,
                   v_cache: torch.Tensor, rope_local: bool = False) -> None:
-    _not_chained("rope_kvappend")
     _rows(qkv, "rope_kvappend")
     if cos.dtype != torch.float16 or sin.dtype != torch.float16 or not cos.is_contiguous() or not sin.is_contiguous():
         raise ParrotHipError("rope_kvappend: the RoPE tables must be contiguous fp16 (lit_gpt/model.py:325-326)")
@@ -302,7 +215,6 @@ def attn_workspace(M: int, n_head: int, hs: int, nsplit: int, device) -> torch.T
 
 def attn_decode(q: torch.Tensor, pos: torch.Tensor, k_cache: torch.Tensor, v_cache: torch.Tensor, n_groups: int,
                 q_per_kv: int, hs: int, S: int, nsplit: int, workspace: torch.Tensor, y: torch.Tensor) -> torch.Tensor:
-    _not_chained("attn_decode")
     _rows(y, "attn_decode")
     M = y.shape[0]
     check(_hip.load().parrot_attn_decode(ptr(q), M, ptr(pos), ptr(k_cache), ptr(v_cache), n_groups, q_per_kv, hs, S,
@@ -318,33 +230,16 @@ def attn_fused_decode(qkv: torch.Tensor, cos: torch.Tensor, sin: torch.Tensor, n
     if qkv.shape[0] != 1 or tickets.dtype != torch.int32 or tickets.numel() < n_groups * q_per_kv:
         raise ParrotHipError("attn_fused_decode: one row, int32 tickets[n_groups] expected")
     lib = _hip.load()
-    if ACTIVE_CHAIN is not None:
-        d, st = ACTIVE_CHAIN.next()
-        check(lib.parrot_attn_fused_decode_chained(ptr(qkv), ptr(cos), ptr(sin), n_elem, ptr(pos), n_groups, q_per_kv, hs,
-                                                   S, nsplit, ptr(workspace), ptr(tickets), ptr(k_cache), ptr(v_cache),
-                                                   ptr(y), C.byref(d), st), "parrot_attn_fused_decode_chained")
-        ACTIVE_CHAIN.done()
-        return y
     check(lib.parrot_attn_fused_decode(ptr(qkv), ptr(cos), ptr(sin), n_elem, ptr(pos), n_groups, q_per_kv, hs, S,
                                        nsplit, ptr(workspace), ptr(tickets), ptr(k_cache), ptr(v_cache), ptr(y),
                                        stream()), "parrot_attn_fused_decode")
     return y
 
 
-CHAIN_MAX_WGS = 256  # co-residency rule of chained launches
-
-
-def attn_nsplit_chained(n_groups: int, S: int, q_per_kv: int = 1) -> int:
-    """Sequence splits of the chained fused-attention launch: as ``attn_nsplit`` but at most 256 workgroups in all."""
-    chunks = (q_per_kv + 3) // 4 if q_per_kv > 2 else 1
-    return max(1, min(attn_nsplit(n_groups, S, q_per_kv), CHAIN_MAX_WGS // (n_groups * chunks)))
-
-
 FUSED_ATTN_MAX_Q_PER_KV = 16
 
 # ------------------------------------------------------------------------------------------------ step glue
 def embedding(wte: torch.Tensor, tokens: torch.Tensor, pos: Optional[torch.Tensor], M: int, out: torch.Tensor) -> torch.Tensor:
-    _not_chained("embedding")
     _rows(out, "embedding")
     if wte.dtype != torch.bfloat16 or not wte.is_contiguous() or tokens.dtype != torch.int64:
         raise ParrotHipError("embedding: wte must be contiguous bf16 and tokens int64")
@@ -354,7 +249,6 @@ def embedding(wte: torch.Tensor, tokens: torch.Tensor, pos: Optional[torch.Tenso
 
 
 def argmax_advance(logits: torch.Tensor, tokens: torch.Tensor, pos: torch.Tensor) -> None:
-    _not_chained("argmax_advance")
     if logits.dtype != torch.bfloat16 or tokens.dtype != torch.int64 or pos.dtype != torch.int32:
         raise ParrotHipError("argmax_advance: logits bf16, tokens int64, pos int32 expected")
     check(_hip.load().parrot_argmax_advance(ptr(logits), logits.numel(), ptr(tokens), ptr(pos), stream()),

@@ -39,15 +39,12 @@ def main():
     ap.add_argument("--iters", type=int, default=200)
     ap.add_argument("--group", type=int, default=128)
     ap.add_argument("--norm", type=int, default=0, help="1: fuse an RMSNorm prologue")
-    ap.add_argument("--knob", type=int, default=0)
     ap.add_argument("--burst-only", type=int, default=0, help="1: sweep only the burst kernel's row groups per workgroup")
     ap.add_argument("--stamps", type=int, default=0, help="1: print in-kernel phase stamps of 3 workgroups (diagnostic)")
     args = ap.parse_args()
     cfg = Config.from_name(args.config)
     lib = _hip.load()
     tune = getattr(lib, "parrot_tune_w4_rows_per_wg", None)
-    if args.knob:
-        lib.parrot_tune_w4_knob(args.knob)
     shapes = cfg.linear_shapes()
     for name, (N, K) in shapes.items():
         if args.mode == "w4":
@@ -72,7 +69,7 @@ def main():
         tune_stream = getattr(lib, "parrot_tune_w4_stream", None)
         variants = [(0, 0, 0), (1, 2, 1), (1, 2, 2), (1, 2, 4), (1, 4, 1), (1, 4, 2), (1, 3, 2), (1, 6, 2), (1, 8, 1)] if args.mode == "w4" and tune_stream is not None else [(0, 0, 0)]
         if args.burst_only:
-            variants = [(0, 0, 0)]
+            variants = [(0, 0, 0), (0, 0, 1), (0, 0, 2), (0, 0, 3), (0, 0, 4)]
         for use_stream, gx, rows in variants:
             if tune is not None:
                 tune(rows)
@@ -115,8 +112,6 @@ def main():
                 t0 = float(d[:, 0].min())
                 for b, nm in enumerate(("first wg", "middle wg", "last wg")):
                     r = d[b]
-                    if args.norm:
-                        print(f"    {nm:9s}   norm: stat done +{float(r[5] - r[0]):5.2f} | block sum {float(r[6] - r[5]):5.2f} | scale+apply+LDS write {float(r[7] - r[6]):5.2f} | barrier+LDS read+xs {float(r[1] - r[7]):5.2f}")
                     print(f"    {nm:9s} entry +{float(r[0]) - t0:5.2f}us | x/norm ready {float(r[1] - r[0]):5.2f} | dots {float(r[2] - r[1]):5.2f} | barrier {float(r[3] - r[2]):5.2f} | epilogue {float(r[4] - r[3]):5.2f} | exit at +{float(r[4]) - t0:5.2f}")
             b = algo * (2 if dual else 1)
             print(f"{name:10s}{'+fc_2' if dual else '     '} N={N:6d} K={K:6d} stream={use_stream} G={128 * gx:4d} wps={rows}  {us:7.2f} us/launch  {b / us / 1e3:7.1f} GB/s  ({b / 1e6:.1f} MB)")
