@@ -27,6 +27,7 @@ bf16_gemv_kernel(const uint4* __restrict__ W, const uint4* __restrict__ W2, cons
     extern __shared__ __attribute__((aligned(16))) unsigned char dense_smem[];  // normalised activations [M][K] bf16 (norm only)
     __shared__ float red[2][MAXW][RU * M * NW];
     __shared__ float stat[16];
+    __builtin_amdgcn_s_setprio(3);  // prologue at raised priority, see w4.hip
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int nwaves = nslabs * wps;
@@ -151,6 +152,7 @@ bf16_gemv_kernel(const uint4* __restrict__ W, const uint4* __restrict__ W2, cons
             }
     }
 
+    __builtin_amdgcn_s_setprio(0);
     const bf16_t* res_p = residual != nullptr ? residual : reinterpret_cast<const bf16_t*>(W);
     const bf16_t* bias_p = bias != nullptr ? bias : reinterpret_cast<const bf16_t*>(W);
     const int e_m = threadIdx.x % M, e_ur = threadIdx.x / M;
@@ -167,6 +169,11 @@ bf16_gemv_kernel(const uint4* __restrict__ W, const uint4* __restrict__ W2, cons
                 DENSE_ISSUE_ROW(t + 1, u + PRIME - RU)
             }
             asm volatile("" ::: "memory");
+            if (RU >= 4) {  // waves that are behind run at higher priority than waves that are ahead
+                if (u == 0) __builtin_amdgcn_s_setprio(2);
+                if (u == RU / 4) __builtin_amdgcn_s_setprio(1);
+                if (u == RU / 2) __builtin_amdgcn_s_setprio(0);
+            }
             float part[NW][M];
 #pragma unroll
             for (int q = 0; q < NW; ++q)

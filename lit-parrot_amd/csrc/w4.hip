@@ -123,6 +123,11 @@ w4_gemv_kernel(const uint4* __restrict__ W, const uint4* __restrict__ W2, const 
     __shared__ float stat[16];
 
     w4_stamp(dbg, 0);
+    // The prologue (activations, fused norm) runs at raised wave priority: the SIMDs arbitrate oldest-first, so without it
+    // the 3rd / 4th workgroup of a CU gets its norm instructions in only when the older workgroups' dot loops stall
+    // (measured: norm ready at +3.4 us in the first workgroup of a CU, +7.5 .. +10 us in the last), and the launch ends
+    // when the slowest workgroup does.  Priority drops back before the dot loop.
+    __builtin_amdgcn_s_setprio(3);
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int nwaves = plan.nslabs * wps;
@@ -278,6 +283,7 @@ w4_gemv_kernel(const uint4* __restrict__ W, const uint4* __restrict__ W2, const 
         xs[m] = s;
     }
     w4_stamp(dbg, 1);
+    __builtin_amdgcn_s_setprio(0);
 
     // bias / residual elements of the epilogue threads: requested at the START of a batch (every thread, clamped, always:
     // a load behind a condition would cost the compiler its static vmcnt bookkeeping), so that the kernel's tail does not
@@ -299,6 +305,13 @@ w4_gemv_kernel(const uint4* __restrict__ W, const uint4* __restrict__ W2, const 
                 W4_ISSUE_ROW(t + 1, u + PRIME - RU)
             }
             asm volatile("" ::: "memory");
+            // waves that are behind run at higher priority than waves that are ahead (the SIMD's default is oldest first,
+            // which lets the first workgroup of a CU finish early and leaves its share of the memory queue idle)
+            if (RU >= 4) {
+                if (u == 0) __builtin_amdgcn_s_setprio(2);
+                if (u == RU / 4) __builtin_amdgcn_s_setprio(1);
+                if (u == RU / 2) __builtin_amdgcn_s_setprio(0);
+            }
             // consume row u (its registers are re-filled PRIME steps later at the earliest ... by row u + PRIME - RU of the
             // next batch, which is only requested after this use)
             float part[NW][M];
