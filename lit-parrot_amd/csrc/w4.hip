@@ -308,9 +308,10 @@ w4_gemv_kernel(const uint4* __restrict__ W, const uint4* __restrict__ W2, const 
             // waves that are behind run at higher priority than waves that are ahead (the SIMD's default is oldest first,
             // which lets the first workgroup of a CU finish early and leaves its share of the memory queue idle)
             if (RU >= 4) {
-                if (u == 0) __builtin_amdgcn_s_setprio(2);
-                if (u == RU / 4) __builtin_amdgcn_s_setprio(1);
-                if (u == RU / 2) __builtin_amdgcn_s_setprio(0);
+                if (u == 0) __builtin_amdgcn_s_setprio(3);
+                if (u == RU / 4) __builtin_amdgcn_s_setprio(2);
+                if (u == RU / 2) __builtin_amdgcn_s_setprio(1);
+                if (u == (3 * RU) / 4) __builtin_amdgcn_s_setprio(0);
             }
             // consume row u (its registers are re-filled PRIME steps later at the earliest ... by row u + PRIME - RU of the
             // next batch, which is only requested after this use)
