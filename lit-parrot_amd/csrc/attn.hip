@@ -226,14 +226,24 @@ __device__ __forceinline__ float load_agent(const float* p) {
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// diagnostic stamps (tools/microbench.py --attn): 100 MHz clock of workgroup (0,0,0) at phase boundaries; the buffer
+// pointer is a kernel argument (a scalar load - see w4.hip for why it must not be a global)
+__device__ __forceinline__ void attn_stamp(unsigned long long* dbg, int i) {
+    if (dbg != nullptr && threadIdx.x == 0 && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0)
+        dbg[i] = __builtin_amdgcn_s_memrealtime();
+}
+static unsigned long long* g_attn_dbg_host = nullptr;
+
 template <int HS, int HQ, int WAVES>
 __global__ void __launch_bounds__(WAVES * 64)
 attn_fused_decode_kernel(const bf16_t* __restrict__ qkv, const __half* __restrict__ rope_cos,
                          const __half* __restrict__ rope_sin, int n_elem, const int32_t* __restrict__ pos_ptr,
                          bf16_t* __restrict__ k_cache, bf16_t* __restrict__ v_cache, int n_groups, int q_per_kv, int S,
-                         int nsplit, float* __restrict__ ws, unsigned int* __restrict__ tickets, bf16_t* __restrict__ y) {
+                         int nsplit, float* __restrict__ ws, unsigned int* __restrict__ tickets, bf16_t* __restrict__ y,
+                         unsigned long long* dbg) {
     constexpr int LPR = HS / 8;
     constexpr int RPW = 64 / LPR;
+    attn_stamp(dbg, 0);
     __shared__ float sh_acc[HQ][WAVES][HS];  // one merged state per wave
     __shared__ float sh_m[HQ][WAVES], sh_l[HQ][WAVES];
     __shared__ float sh_q[kFusedMaxQ][HS];  // roped, bf16-rounded, pre-scaled by 1/sqrt(hs)
@@ -302,6 +312,7 @@ attn_fused_decode_kernel(const bf16_t* __restrict__ qkv, const __half* __restric
         }
     }
     __syncthreads();
+    attn_stamp(dbg, 1);
     // ---- KV append by the workgroup that owns the new slot
     if (blockIdx.z == 0 && slot_new >= s_begin && slot_new < s_begin + per && threadIdx.x < 2 * LPR) {
         const int which = threadIdx.x / LPR, c = threadIdx.x % LPR;
@@ -370,6 +381,7 @@ attn_fused_decode_kernel(const bf16_t* __restrict__ qkv, const __half* __restric
             kv_cur = kv_nxt;
             vv_cur = vv_nxt;
         }
+        attn_stamp(dbg, 2);
         // merge the RPW row slots of this wave with xor shuffles (fixed order), then one state per wave goes to LDS
 #pragma unroll
         for (int hh = 0; hh < HQ; ++hh) {
@@ -394,6 +406,7 @@ attn_fused_decode_kernel(const bf16_t* __restrict__ qkv, const __half* __restric
             }
         }
         __syncthreads();
+        attn_stamp(dbg, 3);
         for (int idx = threadIdx.x; idx < HQ * HS; idx += WAVES * 64) {
             const int hh = idx / HS, d = idx % HS;
             if (h0 + hh < q_per_kv) {
@@ -421,6 +434,7 @@ attn_fused_decode_kernel(const bf16_t* __restrict__ qkv, const __half* __restric
             }
         }
     }
+    attn_stamp(dbg, 4);
     if (nsplit == 1) return;
     // ---- arrival ticket: the last workgroup of this group merges the splits
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every storing wave drains its write-through stores
@@ -462,7 +476,7 @@ static int attn_fused_launch(const void* qkv, const void* cosp, const void* sinp
 #define PARROT_FUSED_GO(HQV, WV)                                                                                        \
     return launch(K_ATTN_FUSED, attn_fused_decode_kernel<HS, HQV, WV>, grid, block, 0, st, (const bf16_t*)qkv,          \
                   (const __half*)cosp, (const __half*)sinp, n_elem, pos, (bf16_t*)k_cache, (bf16_t*)v_cache, n_groups,   \
-                  q_per_kv, S, nsplit, (float*)ws, (unsigned int*)tickets, (bf16_t*)y)
+                  q_per_kv, S, nsplit, (float*)ws, (unsigned int*)tickets, (bf16_t*)y, g_attn_dbg_host)
     if (wide) {
         if (q_per_kv == 1) PARROT_FUSED_GO(1, 16);
         if (q_per_kv == 2) PARROT_FUSED_GO(2, 16);
@@ -515,6 +529,11 @@ int parrot_qkv_rope_kvappend(const void* qkv, int ldqkv, int M, const void* rope
     return launch(K_ROPE_KVAPPEND, rope_kvappend_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
                   (hipStream_t)stream, (const bf16_t*)qkv, ldqkv, M, (const __half*)rope_cos, (const __half*)rope_sin,
                   n_elem, rope_local, pos, n_groups, q_per_kv, hs, S, (bf16_t*)q_out, (bf16_t*)k_cache, (bf16_t*)v_cache);
+}
+
+int parrot_tune_attn_stamps(void* dbg8_u64) {  // diagnostic: device buffer of 8 uint64, or NULL to switch off
+    g_attn_dbg_host = (unsigned long long*)dbg8_u64;
+    return PARROT_OK;
 }
 
 int parrot_attn_fused_decode(const void* qkv, const void* rope_cos, const void* rope_sin, int n_elem, const int32_t* pos,
