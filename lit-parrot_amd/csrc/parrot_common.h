@@ -149,6 +149,31 @@ __device__ __forceinline__ float wave_sum_to_lane63(float v) {
     v += dpp0<0x143, 0xC>(v);  // row_bcast31 into rows 2 and 3
     return v;
 }
+// Eight wave sums at once: p[g] summed over the 64 lanes, the total of p[g] valid in the 8 lanes 8g .. 8g+7.
+// gfx950 lane-swap instructions pack two half-reduced values into one register per step (v_permlane32_swap: a's upper 32
+// lanes <-> b's lower 32; v_permlane16_swap: odd 16-lane rows of a <-> even rows of b), so the whole thing is 18
+// instructions instead of 8 x 13 for eight separate wave_sum_to_lane63 calls.
+__device__ __forceinline__ float swap_add32(float a, float b) {
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);  // [a.lo + a.hi | b.lo + b.hi]
+}
+__device__ __forceinline__ float swap_add16(float a, float b) {
+    const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(a), __float_as_uint(b), false, false);
+    return __uint_as_float(r[0]) + __uint_as_float(r[1]);  // rows: [a0 + a1 | b0 + b1 | a2 + a3 | b2 + b3]
+}
+__device__ __forceinline__ float wave_sum8(const float (&p)[8]) {
+    const float s0 = swap_add32(p[0], p[4]), s1 = swap_add32(p[1], p[5]);
+    const float s2 = swap_add32(p[2], p[6]), s3 = swap_add32(p[3], p[7]);
+    float z0 = swap_add16(s0, s2);  // 16-lane rows: p0 | p2 | p4 | p6
+    float z1 = swap_add16(s1, s3);  //               p1 | p3 | p5 | p7
+    z0 += dpp0<0x128>(z0);          // row_ror:8 - both halves of a row hold the 8 pair sums
+    z1 += dpp0<0x128>(z1);
+    float w = (threadIdx.x & 8) ? z1 : z0;  // 8-lane group g = 2 * row + half holds p[g]
+    w += dpp0<0x141>(w);                    // row_half_mirror
+    w += dpp0<0xB1>(w);                     // quad_perm [1,0,3,2]
+    w += dpp0<0x4E>(w);                     // quad_perm [2,3,0,1]
+    return w;
+}
 __device__ __forceinline__ int wave_sum_i32_to_lane63(int v) {
     v += __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xF, 0xF, true);
     v += __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xF, 0xF, true);

@@ -291,6 +291,8 @@ w4_gemv_kernel(const uint4* __restrict__ W, const uint4* __restrict__ W2, const 
     const bf16_t* res_p = residual != nullptr ? residual : reinterpret_cast<const bf16_t*>(W);
     const bf16_t* bias_p = bias != nullptr ? bias : reinterpret_cast<const bf16_t*>(W);
     const int e_m = threadIdx.x % M, e_ur = threadIdx.x / M;
+    constexpr bool kSum8 = (M == 1 && RU == 8);  // eight row sums in one packed reduction (wave_sum8)
+    float lanep[NW][8];
     for (int t = 0; t < iters; ++t) {
         float(*rd)[RU * M * NW] = red[t & 1];
         const int e_col = min(((int)blockIdx.x + t * (int)gridDim.x) * R + e_ur, N - 1);
@@ -323,14 +325,33 @@ w4_gemv_kernel(const uint4* __restrict__ W, const uint4* __restrict__ W2, const 
 #pragma unroll
                 for (int m = 0; m < M; ++m) {
                     const float p = w4_slice_dot(w[q][u], xr[m]);
-                    part[q][m] = wave_sum_to_lane63(s * (p - zz * xs[m]));
+                    if constexpr (kSum8)
+                        lanep[q][u & 7] = s * (p - zz * xs[m]);  // all eight rows are reduced together after the batch
+                    else
+                        part[q][m] = wave_sum_to_lane63(s * (p - zz * xs[m]));
                 }
             }
+            if constexpr (!kSum8) {
 #pragma unroll
-            for (int q = 0; q < NW; ++q)
+                for (int q = 0; q < NW; ++q)
 #pragma unroll
-                for (int m = 0; m < M; ++m)
-                    if (lane == 63) rd[wave][(u * M + m) * NW + q] = part[q][m];
+                    for (int m = 0; m < M; ++m)
+                        if (lane == 63) rd[wave][(u * M + m) * NW + q] = part[q][m];
+            } else {
+                // without the per-row reduction (and its LDS store) nothing anchors a row's arithmetic between the load
+                // requests any more: the compiler sinks all eight dot products below the last request - every row's
+                // weights live at once (195 - 256 VGPRs, spills) and no compute under the loads.  Pin the row's result
+                // to this point of the request sequence.
+#pragma unroll
+                for (int q = 0; q < NW; ++q) asm volatile("" : "+v"(lanep[q][u & 7])::"memory");
+            }
+        }
+        if constexpr (kSum8) {
+#pragma unroll
+            for (int q = 0; q < NW; ++q) {
+                const float tot = wave_sum8(lanep[q]);
+                if ((lane & 7) == 0) rd[wave][(lane >> 3) * NW + q] = tot;  // row u = lane / 8 (M = 1)
+            }
         }
         if (t == 0) w4_stamp(dbg, 2);
         __syncthreads();
