@@ -19,17 +19,46 @@ embedding_kernel(const uint4* __restrict__ wte, int d16, const int64_t* __restri
 // lowest index wins.)  Single workgroup; then the loop state advances: tokens[pos+1] = best, pos += 1.
 constexpr int kArgmaxThreads = 1024;
 __global__ void __launch_bounds__(kArgmaxThreads)
-argmax_advance_kernel(const bf16_t* __restrict__ logits, int V, int64_t* __restrict__ tokens, int32_t* __restrict__ pos_ptr) {
+argmax_advance_kernel(const bf16_t* __restrict__ logits, int V, int vec, int64_t* __restrict__ tokens, int32_t* __restrict__ pos_ptr) {
     __shared__ float sv[kArgmaxThreads / 64];
     __shared__ int si[kArgmaxThreads / 64];
     float best = -INFINITY;
     int bi = 0x7fffffff;
-    for (int i = threadIdx.x; i < V; i += kArgmaxThreads) {
-        float v = bf2f(logits[i]);
-        if (v != v) v = -INFINITY;  // a NaN logit never wins
-        if (bi == 0x7fffffff || v > best) {  // indices ascend per thread, so ties keep the lowest
-            best = v;
-            bi = i;
+    // 16-byte chunks (8 logits), thread t owns chunks t, t + 1024, ...: kArgmaxIt of them are requested together
+    // (clamped, unconditional) before the first compare; indices ascend per thread, so ties keep the lowest.
+    // (The row must be 16-byte aligned: checked on the host; a ragged tail is masked by index.)
+    constexpr int kArgmaxIt = 4;
+    const int chunks = (V + 7) >> 3;
+    const uint4* lg = reinterpret_cast<const uint4*>(logits);
+    if (!vec) {  // fewer than 8 logits or an unaligned row: element loads
+        for (int i = threadIdx.x; i < V; i += kArgmaxThreads) {
+            float v = bf2f(logits[i]);
+            if (v != v) v = -INFINITY;
+            if (bi == 0x7fffffff || v > best) {
+                best = v;
+                bi = i;
+            }
+        }
+    }
+    for (int c0 = threadIdx.x; vec && c0 < chunks; c0 += kArgmaxThreads * kArgmaxIt) {
+        uint4 v4[kArgmaxIt];
+#pragma unroll
+        for (int k = 0; k < kArgmaxIt; ++k) v4[k] = lg[min(c0 + k * kArgmaxThreads, (V >> 3) - 1)];
+#pragma unroll
+        for (int k = 0; k < kArgmaxIt; ++k) {
+            const int c = c0 + k * kArgmaxThreads;
+            const uint32_t dw[4] = {v4[k].x, v4[k].y, v4[k].z, v4[k].w};
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int i = c * 8 + e;
+                float v = (e & 1) ? bfhi(dw[e >> 1]) : bflo(dw[e >> 1]);
+                if (c >= (V >> 3)) v = (i < V) ? bf2f(logits[i < V ? i : 0]) : -INFINITY;  // ragged tail chunk: element loads
+                if (v != v) v = -INFINITY;  // a NaN logit never wins
+                if (i < V && (bi == 0x7fffffff || v > best)) {
+                    best = v;
+                    bi = i;
+                }
+            }
         }
     }
 #pragma unroll
@@ -105,8 +134,9 @@ int parrot_prefetch(const void* data, int64_t bytes, int workgroups, void* strea
 int parrot_argmax_advance(const void* logits, int V, int64_t* tokens, int32_t* pos, void* stream) {
     PARROT_REQUIRE(logits && tokens && pos, "argmax_advance: null pointer");
     PARROT_REQUIRE(V >= 1, "argmax_advance: V=%d", V);
+    const int vec = (V >= 8 && aligned16(logits)) ? 1 : 0;
     return launch(K_ARGMAX, argmax_advance_kernel, dim3(1), dim3(kArgmaxThreads), 0, (hipStream_t)stream,
-                  (const bf16_t*)logits, V, tokens, pos);
+                  (const bf16_t*)logits, V, vec, tokens, pos);
 }
 
 }  // extern "C"

@@ -474,6 +474,22 @@ def test_embedding_and_argmax_advance():
     assert torch.equal(out[:2].cpu(), wte[tokens[3:5]])
     # argmax: unique maximum, then a tie (lowest index wins), then a NaN that must not win
     tok_d = tokens.to(DEV)
+    # ragged tail (V % 8 != 0), fewer than 8 logits, an unaligned row, an all-NaN row
+    for V, off in ((5, 0), (13, 0), (301, 0), (4099, 0), (64, 1)):
+        buf = torch.randn(V + off, generator=g).to(BF)
+        buf[off + V - 1] = 7.0
+        pos = torch.tensor([4], dtype=torch.int32, device=DEV)
+        ops.argmax_advance(buf.to(DEV)[off:], tok_d, pos)
+        assert int(tok_d[5]) == V - 1, (V, off, int(tok_d[5]))
+        if V > 2:
+            buf[off + 1] = 7.0  # tie: lowest index
+            pos = torch.tensor([4], dtype=torch.int32, device=DEV)
+            ops.argmax_advance(buf.to(DEV)[off:], tok_d, pos)
+            assert int(tok_d[5]) == 1, (V, off, int(tok_d[5]))
+    pos = torch.tensor([4], dtype=torch.int32, device=DEV)
+    ops.argmax_advance(torch.full((40,), float("nan")).to(BF).to(DEV), tok_d, pos)
+    assert int(tok_d[5]) == 0
+    tok_d[5:7] = 0
     for V in (300, 32000, 50304):
         logits = torch.randn(V, generator=g).to(BF)
         logits[V - 7] = 9.0
