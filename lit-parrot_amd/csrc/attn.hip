@@ -226,6 +226,36 @@ __device__ __forceinline__ float load_agent(const float* p) {
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// sum over the LPR lanes that share a key row (LPR = 4, 8 or 16 consecutive lanes); every lane of the group gets the
+// total.  DPP only: no LDS crossbar (ds_bpermute) and no lgkmcnt waits in the key loop's dependent chain.
+template <int LPR>
+__device__ __forceinline__ float group_sum(float v) {
+    v += dpp0<0xB1>(v);                    // quad_perm [1,0,3,2]
+    v += dpp0<0x4E>(v);                    // quad_perm [2,3,0,1]
+    if (LPR >= 8) v += dpp0<0x141>(v);     // row_half_mirror: the two quads of an 8-lane group
+    if (LPR >= 16) v += dpp0<0x128>(v);    // row_ror:8: the two halves of a 16-lane row
+    return v;
+}
+
+// all-reduce over the 64 / LPR row slots of a wave (lanes with the same lane % LPR): DPP rotations inside the 16-lane rows,
+// then the gfx950 lane swaps across rows (v_permlane16_swap / v_permlane32_swap with both operands the same register
+// return the two halves, which are then combined) - no ds_bpermute.
+template <int LPR, bool MAX>
+__device__ __forceinline__ float slot_allreduce(float v) {
+    auto op = [](float a, float b) { return MAX ? fmaxf(a, b) : a + b; };
+    if (LPR <= 4) v = op(v, dpp0<0x124>(v));  // row_ror:4
+    if (LPR <= 8) v = op(v, dpp0<0x128>(v));  // row_ror:8 - every lane now holds its 16-lane row's result
+    {
+        const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+        v = op(__uint_as_float(r[0]), __uint_as_float(r[1]));  // rows 0+1 and 2+3
+    }
+    {
+        const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+        v = op(__uint_as_float(r[0]), __uint_as_float(r[1]));  // both halves
+    }
+    return v;
+}
+
 // diagnostic stamps (tools/microbench.py --attn): 100 MHz clock of workgroup (0,0,0) at phase boundaries; the buffer
 // pointer is a kernel argument (a scalar load - see w4.hip for why it must not be a global)
 __device__ __forceinline__ void attn_stamp(unsigned long long* dbg, int i) {
@@ -246,7 +276,7 @@ attn_fused_decode_kernel(const bf16_t* __restrict__ qkv, const __half* __restric
     attn_stamp(dbg, 0);
     __shared__ float sh_acc[HQ][WAVES][HS];  // one merged state per wave
     __shared__ float sh_m[HQ][WAVES], sh_l[HQ][WAVES];
-    __shared__ float sh_q[kFusedMaxQ][HS];  // roped, bf16-rounded, pre-scaled by 1/sqrt(hs)
+    __shared__ __attribute__((aligned(16))) bf16_t sh_q[kFusedMaxQ][HS];  // roped q rows as bf16 (the scale is applied to the score)
     __shared__ __attribute__((aligned(16))) bf16_t sh_kv[2][HS];  // roped k_new, v_new as stored in the cache
     __shared__ int sh_last;
 
@@ -289,12 +319,10 @@ attn_fused_decode_kernel(const bf16_t* __restrict__ qkv, const __half* __restric
         }
     }
     const int s_first = s_begin + wave * RPW;
-    uint4 kv_cur = make_uint4(0, 0, 0, 0), vv_cur = kv_cur;
-    if (s_first < s_end) {
-        const int sc = min(s_first + sub, s_end - 1);
-        kv_cur = kc[(int64_t)sc * LPR + dl];
-        vv_cur = vc[(int64_t)sc * LPR + dl];
-    }
+    // first K/V rows of this wave: requested here, before the RoPE phase (clamped, unconditional)
+    const int sc_first = min(s_first + sub, max(s_end - 1, 0));
+    const uint4 kv_cur = kc[(int64_t)sc_first * LPR + dl];
+    const uint4 vv_cur = vc[(int64_t)sc_first * LPR + dl];
 
     // ---- split + RoPE of this group's rows (reference model.py:208-232): x*cos + rotate_half(x)*sin, each product and
     // the sum rounded to fp32 separately; elements outside the rotary part pass through (cos = 1, sin = 0 is exact)
@@ -306,7 +334,7 @@ attn_fused_decode_kernel(const bf16_t* __restrict__ qkv, const __half* __restric
             const float v = __fadd_rn(__fmul_rn(rx[it], rc[it]), __fmul_rn(ro[it], rs[it]));
             const bf16_t vb = f2bf(v);
             if (t < q_per_kv)
-                sh_q[t][d] = bf2f(vb) * scale;
+                sh_q[t][d] = vb;
             else
                 sh_kv[t - q_per_kv][d] = vb;
         }
@@ -323,79 +351,76 @@ attn_fused_decode_kernel(const bf16_t* __restrict__ qkv, const __half* __restric
     const uint4 vnew = reinterpret_cast<const uint4*>(sh_kv[1])[dl];
 
     {
-        float qf[HQ][8];
+        uint32_t qp[HQ][4];  // this lane's 8 dims of every query head, packed bf16 pairs (operand of v_dot2_f32_bf16)
         float mrun[HQ], lrun[HQ], acc[HQ][8];
 #pragma unroll
         for (int hh = 0; hh < HQ; ++hh) {
             const int hq = min(h0 + hh, q_per_kv - 1);
-#pragma unroll
-            for (int e = 0; e < 8; ++e) qf[hh][e] = sh_q[hq][dl * 8 + e];
+            const uint4 qv = reinterpret_cast<const uint4*>(sh_q[hq])[dl];
+            qp[hh][0] = qv.x;
+            qp[hh][1] = qv.y;
+            qp[hh][2] = qv.z;
+            qp[hh][3] = qv.w;
             mrun[hh] = -INFINITY;
             lrun[hh] = 0.f;
 #pragma unroll
             for (int e = 0; e < 8; ++e) acc[hh][e] = 0.f;
         }
-        for (int s0 = s_first; s0 < s_end; s0 += STRIDE) {
-            // software pipeline: request the next rows before working on the current ones
-            uint4 kv_nxt = kv_cur, vv_nxt = vv_cur;
-            if (s0 + STRIDE < s_end) {
-                const int sn = min(s0 + STRIDE + sub, s_end - 1);
-                kv_nxt = kc[(int64_t)sn * LPR + dl];
-                vv_nxt = vc[(int64_t)sn * LPR + dl];
-            }
-            const int s = s0 + sub;
+        const int s_last = max(s_end - 1, 0);
+        // one step = the STRIDE keys of the workgroup; this lane: key s, dims 8*dl .. 8*dl+7
+        auto step = [&](uint4 kv, uint4 vv, int s) {
             const bool ok = s < s_end;
-            const int sc = ok ? s : s_end - 1;
-            uint4 kv = kv_cur, vv = vv_cur;
-            if (sc == slot_new) {  // the row being appended by this launch: use the in-register copy
+            if ((ok ? s : s_last) == slot_new) {  // the row being appended by this launch: use the in-register copy
                 kv = knew;
                 vv = vnew;
             }
-            const uint32_t kd[4] = {kv.x, kv.y, kv.z, kv.w};
             const uint32_t vd[4] = {vv.x, vv.y, vv.z, vv.w};
-            float kf[8], vf[8];
+            float vf[8];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                kf[2 * j] = bflo(kd[j]);
-                kf[2 * j + 1] = bfhi(kd[j]);
-                vf[2 * j] = bflo(vd[j]);
-                vf[2 * j + 1] = bfhi(vd[j]);
+            for (int jq = 0; jq < 4; ++jq) {
+                vf[2 * jq] = bflo(vd[jq]);
+                vf[2 * jq + 1] = bfhi(vd[jq]);
             }
 #pragma unroll
             for (int hh = 0; hh < HQ; ++hh) {
-                float sc_ = 0.f;
+                // q.k over this lane's 8 dims straight from the packed bf16 pairs, then over the LPR lanes of the key
+                float p0 = dot2_bf16(kv.x, qp[hh][0], 0.f), p1 = dot2_bf16(kv.y, qp[hh][1], 0.f);
+                p0 = dot2_bf16(kv.z, qp[hh][2], p0);
+                p1 = dot2_bf16(kv.w, qp[hh][3], p1);
+                const float sc_ = ok ? group_sum<LPR>(p0 + p1) * scale : -INFINITY;  // a masked key never raises the maximum
+                const float mn = fmaxf(mrun[hh], sc_);
+                const float corr = (mn == -INFINITY) ? 1.f : __expf(mrun[hh] - mn);
+                const float p = (mn == -INFINITY) ? 0.f : __expf(sc_ - mn);
+                lrun[hh] = lrun[hh] * corr + p;
 #pragma unroll
-                for (int e = 0; e < 8; ++e) sc_ = fmaf(qf[hh][e], kf[e], sc_);
-#pragma unroll
-                for (int off = LPR / 2; off >= 1; off >>= 1) sc_ += __shfl_xor(sc_, off, 64);
-                if (ok) {
-                    const float mn = fmaxf(mrun[hh], sc_);
-                    const float corr = __expf(mrun[hh] - mn);
-                    const float p = __expf(sc_ - mn);
-                    lrun[hh] = lrun[hh] * corr + p;
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) acc[hh][e] = acc[hh][e] * corr + p * vf[e];
-                    mrun[hh] = mn;
-                }
-            }
-            kv_cur = kv_nxt;
-            vv_cur = vv_nxt;
-        }
-        attn_stamp(dbg, 2);
-        // merge the RPW row slots of this wave with xor shuffles (fixed order), then one state per wave goes to LDS
-#pragma unroll
-        for (int hh = 0; hh < HQ; ++hh) {
-#pragma unroll
-            for (int off = LPR; off < 64; off <<= 1) {
-                const float m_o = __shfl_xor(mrun[hh], off, 64), l_o = __shfl_xor(lrun[hh], off, 64);
-                const float mn = fmaxf(mrun[hh], m_o);
-                const float c1 = (mrun[hh] == -INFINITY) ? 0.f : __expf(mrun[hh] - mn);
-                const float c2 = (m_o == -INFINITY) ? 0.f : __expf(m_o - mn);
-                lrun[hh] = lrun[hh] * c1 + l_o * c2;
-#pragma unroll
-                for (int e = 0; e < 8; ++e) acc[hh][e] = acc[hh][e] * c1 + __shfl_xor(acc[hh][e], off, 64) * c2;
+                for (int e = 0; e < 8; ++e) acc[hh][e] = acc[hh][e] * corr + p * vf[e];
                 mrun[hh] = mn;
             }
+        };
+        // two register sets in ping-pong; every load is unconditional (rows past the range are clamped and masked in
+        // step()): loads behind run-time conditions cost the compiler its vmcnt bookkeeping
+        uint4 k0 = kv_cur, v0 = vv_cur;
+        for (int s0 = s_first; s0 < s_end; s0 += 2 * STRIDE) {
+            const int sn1 = min(s0 + STRIDE + sub, s_last);
+            const uint4 k1 = kc[(int64_t)sn1 * LPR + dl], v1 = vc[(int64_t)sn1 * LPR + dl];
+            step(k0, v0, s0 + sub);
+            const int sn2 = min(s0 + 2 * STRIDE + sub, s_last);
+            k0 = kc[(int64_t)sn2 * LPR + dl];
+            v0 = vc[(int64_t)sn2 * LPR + dl];
+            if (s0 + STRIDE < s_end) step(k1, v1, s0 + STRIDE + sub);  // wave-uniform
+        }
+        attn_stamp(dbg, 2);
+        // merge the RPW row slots of this wave: first the slots' common maximum, then every lane rescales its own state ONCE
+        // and the rest is plain sums (the pairwise merge re-evaluated two exponentials per step and value); one state per
+        // wave goes to LDS
+#pragma unroll
+        for (int hh = 0; hh < HQ; ++hh) {
+            const float mw = slot_allreduce<LPR, true>(mrun[hh]);
+            const float c = (mrun[hh] == -INFINITY) ? 0.f : __expf(mrun[hh] - mw);
+            lrun[hh] = slot_allreduce<LPR, false>(lrun[hh] * c);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) acc[hh][e] = slot_allreduce<LPR, false>(acc[hh][e] * c);
+            mrun[hh] = mw;
             if (sub == 0) {
 #pragma unroll
                 for (int e = 0; e < 8; ++e) sh_acc[hh][wave][dl * 8 + e] = acc[hh][e];
