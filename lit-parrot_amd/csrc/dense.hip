@@ -15,8 +15,8 @@
 
 namespace parrot {
 
-constexpr int kDenseJ = 8;         // 16-B loads per lane per row (max)
-constexpr int kDenseMaxSlabs = 8;  // K <= 32768
+constexpr int kDenseJ = 4;         // 16-B loads per lane per row (max)
+constexpr int kDenseMaxSlabs = 16;  // K <= 32768
 
 template <int M, bool DUAL, int J, int RU, int MAXW>
 __global__ void __launch_bounds__(MAXW * 64)
@@ -215,11 +215,10 @@ bf16_gemv_kernel(const uint4* __restrict__ W, const uint4* __restrict__ W2, cons
 #undef DENSE_ROW0
 }
 
-template <int M, int J>
-static int bf16_gemv_launch_j(const void* W, const void* W2, const void* x, int ldx, const void* bias,
-                              const void* residual, int ldr, void* out, int ldo, int N, int K, int epi, const NormArgs& na,
-                              int nslabs, hipStream_t st) {
-    constexpr int MAXW = 8;
+template <int M, int J, int MAXW>
+static int bf16_gemv_launch_jw(const void* W, const void* W2, const void* x, int ldx, const void* bias,
+                               const void* residual, int ldr, void* out, int ldo, int N, int K, int epi, const NormArgs& na,
+                               int nslabs, hipStream_t st) {
     constexpr int RU = 4, RUD = 2;  // rows per wave and batch (single weight / SwiGLU pair)
     const bool dual = epi == PARROT_EPI_SWIGLU;
     const int ru = dual ? RUD : RU;
@@ -250,6 +249,16 @@ static int bf16_gemv_launch_j(const void* W, const void* W2, const void* x, int 
                   ldo, N, K, wps, nslabs, epi, iters, na);
 }
 
+template <int M, int J>
+static int bf16_gemv_launch_j(const void* W, const void* W2, const void* x, int ldx, const void* bias,
+                              const void* residual, int ldr, void* out, int ldo, int N, int K, int epi, const NormArgs& na,
+                              int nslabs, hipStream_t st) {
+    if (nslabs <= 8) return bf16_gemv_launch_jw<M, J, 8>(W, W2, x, ldx, bias, residual, ldr, out, ldo, N, K, epi, na, nslabs, st);
+    if constexpr (J <= 4) return bf16_gemv_launch_jw<M, J, 16>(W, W2, x, ldx, bias, residual, ldr, out, ldo, N, K, epi, na, nslabs, st);
+    set_error("bf16_gemv: K=%d needs more than 8 slabs of %d loads", K, J);
+    return PARROT_EUNSUPPORTED;
+}
+
 template <int M>
 static int bf16_gemv_launch(const void* W, const void* W2, const void* x, int ldx, const void* bias,
                             const void* residual, int ldr, void* out, int ldo, int N, int K, int epi, const NormArgs& na,
@@ -264,9 +273,6 @@ static int bf16_gemv_launch(const void* W, const void* W2, const void* x, int ld
     PARROT_DENSE_J(2);
     PARROT_DENSE_J(3);
     PARROT_DENSE_J(4);
-    PARROT_DENSE_J(5);
-    PARROT_DENSE_J(6);
-    PARROT_DENSE_J(8);
 #undef PARROT_DENSE_J
     set_error("bf16_gemv: K=%d too large", K);
     return PARROT_EUNSUPPORTED;

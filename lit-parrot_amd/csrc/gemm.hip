@@ -141,9 +141,22 @@ gemm_kernel(const bf16_t* __restrict__ A, int lda, int M, const void* __restrict
         __syncthreads();  // previous pass finished with the LDS stages; xs_l is filled
         stage(0);
         __syncthreads();
+        uint32_t mtg[JN];  // int4: {scale, zero} of the current quantisation group for this lane's output columns
         for (int kt = 0; kt < ktiles; ++kt) {
             const int st = kt & 1;
             const int slab_now = slab;  // slab of tile kt (fetch() below may advance it)
+            if (W4 && kt % Gs == 0) {
+                // requested at the START of the group and used at its end (Gs tiles later): the first version loaded it at
+                // the fold, a full memory latency on the critical path of every group
+                const int g = kt / Gs;
+                const int gs = slab_now;  // the slab of the group's first slice stores the group's metadata
+#pragma unroll
+                for (int jn = 0; jn < JN; ++jn) {
+                    const int64_t gn = min(n0 + wn * (GBN / 2) + jn * 32 + lr, N - 1);
+                    const uint4* rec = reinterpret_cast<const uint4*>(Wp) + gn * plan.row16;
+                    mtg[jn] = reinterpret_cast<const uint32_t*>(rec + plan.slab[gs].meta_off16)[g - plan.slab[gs].g0];
+                }
+            }
             if (kt + 1 < ktiles) fetch(kt + 1);
             // ---- 2 k-steps of MFMA 32x32x16 on stage st
 #pragma unroll
@@ -170,9 +183,7 @@ gemm_kernel(const bf16_t* __restrict__ A, int lda, int M, const void* __restrict
                 const int g = kt / Gs;
 #pragma unroll
                 for (int jn = 0; jn < JN; ++jn) {
-                    const int64_t gn = min(n0 + wn * (GBN / 2) + jn * 32 + lr, N - 1);
-                    const uint4* rec = reinterpret_cast<const uint4*>(Wp) + gn * plan.row16;
-                    const uint32_t mt = reinterpret_cast<const uint32_t*>(rec + plan.slab[slab_now].meta_off16)[g - plan.slab[slab_now].g0];
+                    const uint32_t mt = mtg[jn];
                     const float sc = bflo(mt), zz = 128.0f + bfhi(mt);
 #pragma unroll
                     for (int i = 0; i < IM; ++i)
