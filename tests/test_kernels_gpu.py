@@ -98,6 +98,45 @@ def test_w4_gemv_matches_oracle(N, K, group, M):
     assert float((out.cpu().float() - ref.float()).abs().max()) <= 1e-2 * max(1.0, float(ref.float().abs().max()))
 
 
+@pytest.mark.parametrize("kind", ["w4", "bf16"])
+@pytest.mark.parametrize("N,K,epi,M", [(40000, 128, EPI_NONE, 1), (20003, 256, EPI_SWIGLU, 1), (33001, 128, EPI_RESIDUAL, 3)])
+def test_gemv_workgroups_walk_several_row_batches(kind, N, K, epi, M):
+    """More row batches than resident workgroups: every workgroup walks several batches (lm_head-sized launches), with the
+    rolling window of weight requests crossing the batch boundary, a ragged last batch and a fused norm computed once."""
+    g = gen(41)
+    x = torch.randn(M, K, generator=g).to(BF)
+    res = torch.randn(M, N, generator=g).to(BF) if epi == EPI_RESIDUAL else None
+    nw = (1 + 0.1 * torch.randn(K, generator=g)).to(BF)
+    norm = ops.Norm(1, nw.to(DEV), None, 1e-5)
+    out = torch.empty((M, N), dtype=BF, device=DEV)
+    out2 = torch.empty((M, N), dtype=BF, device=DEV)
+    xnd = torch.empty((M, K), dtype=BF, device=DEV)
+    ops.rmsnorm(x.to(DEV), nw.to(DEV), 1e-5, xnd)
+    if kind == "w4":
+        qw, s, z, tc, Wd = make_w4(N, K, 128, 7)
+        lin = w4_module(qw, s, z, N, K, 128, None)
+        lin2 = None
+        Wd2 = None
+        if epi == EPI_SWIGLU:
+            qw2, s2, z2, _, Wd2 = make_w4(N, K, 128, 8)
+            lin2 = w4_module(qw2, s2, z2, N, K, 128)
+        lin.hip_linear(x.to(DEV), out, epilogue=epi, residual=res.to(DEV) if res is not None else None, partner=lin2, norm=norm)
+        lin.hip_linear(xnd, out2, epilogue=epi, residual=res.to(DEV) if res is not None else None, partner=lin2)
+    else:
+        W = (torch.randn(N, K, generator=g) * 0.05).to(BF)
+        W2 = (torch.randn(N, K, generator=g) * 0.05).to(BF) if epi == EPI_SWIGLU else None
+        Wd, Wd2 = W.double(), (W2.double() if W2 is not None else None)
+        kw = dict(epilogue=epi, residual=res.to(DEV) if res is not None else None, weight2=W2.to(DEV) if W2 is not None else None)
+        ops.bf16_linear(W.to(DEV), x.to(DEV), out, norm=norm, **kw)
+        ops.bf16_linear(W.to(DEV), xnd, out2, **kw)
+    # fused norm == stand-alone norm kernel followed by the same GEMV (bit for bit up to the statistic's summation order)
+    assert float((out.float() - out2.float()).abs().max()) <= 2 ** -6 and float((out == out2).float().mean()) > 0.97
+    # and against float64 on the normalised rows
+    xd = xnd.cpu().double()
+    want = expected_epilogue(xd @ Wd.t(), xd @ Wd2.t() if Wd2 is not None else None, None, res, epi)
+    assert_bf16_close(out2, want, ulps=1, atol=3e-3, what=f"{kind} multi-batch N={N} K={K} epi={epi} M={M}")
+
+
 @pytest.mark.parametrize("M", [1, 2, 4, 5, 9])
 @pytest.mark.parametrize("epi", [EPI_NONE, EPI_RESIDUAL, EPI_GELU, EPI_SWIGLU])
 def test_w4_epilogues_and_row_counts(M, epi):
