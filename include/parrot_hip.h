@@ -111,6 +111,12 @@ int parrot_w8_prep_act(const void* x, int ldx, int M, int K, float threshold, vo
 int parrot_w8_gemv(const void* CB, const void* SCB, const void* xq, const void* xout, const void* sca,
                    const void* nout, const void* oidx, int M, const void* bias, const void* residual, int ldr, void* out,
                    int ldo, int N, int K, int epilogue, void* stream);
+/* The two calls above for ONE token row in one launch (decode): x bf16 [K] -> (optional norm) -> fp16 cast, outlier
+ * split at `threshold`, row-absmax int8 - computed per workgroup in LDS - then the int8 GEMV, the fp16 outlier part and
+ * the epilogue.  Same arithmetic as parrot_w8_prep_act + parrot_w8_gemv; K <= 16384.                                 */
+int parrot_w8_gemv_fused(const void* CB, const void* SCB, const void* x, float threshold, const void* bias,
+                         const void* residual, void* out, int N, int K, int epilogue,
+                         const parrot_norm_t* norm, void* stream);
 
 /* ---- norms (lit_gpt/rmsnorm.py:17-21; torch.nn.LayerNorm via lit_gpt/config.py:86-92) ---- */
 /* rsqrt_mode 0: rsqrt evaluated in fp32 and rounded to bf16 once (what torch's GPU kernels do);

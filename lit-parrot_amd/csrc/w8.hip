@@ -278,6 +278,305 @@ static int w8_launch(const void* CB, const void* CB2, const void* SCB, const voi
                   K, R, epi, nslabs);
 }
 
+// ------------------------------------------------------------------------------------------ fused single-token Linear
+// Decode step (one row): activation quantiser + GEMV in ONE launch, on the structure of the int4 kernel (w4.hip):
+// workgroup = nslabs x wps waves; the prologue (optional norm -> fp16 cast -> outlier split -> row absmax -> int8) is
+// computed once per workgroup into LDS ([K] int8, [K] fp16 outlier values, a compact list of the first kW8Cap outlier
+// columns in a deterministic thread-major order); weight rows go through a rolling window; resident-size grid walking
+// `iters` row batches; wave priorities.  Same arithmetic as w8_prep_act_kernel + w8_gemv_kernel.
+constexpr int kW8Cap = 256;
+
+template <bool DUAL, int J, int RU, int MAXW>
+__global__ void __launch_bounds__(MAXW * 64)
+w8_fused_kernel(const uint4* __restrict__ CB, const uint4* __restrict__ CB2, const float* __restrict__ SCB,
+                const float* __restrict__ SCB2, const bf16_t* __restrict__ x, float threshold,
+                const bf16_t* __restrict__ bias, const bf16_t* residual, bf16_t* out, int N, int K, int wps, int nslabs,
+                int epi, int iters, NormArgs na) {
+    constexpr int NW = DUAL ? 2 : 1;
+    extern __shared__ __attribute__((aligned(16))) unsigned char w8_smem[];  // [K] int8 | [K] fp16
+    __shared__ int red[2][MAXW][RU * NW];
+    __shared__ float stat[16];
+    __shared__ float shmax[16];
+    __shared__ int scan[16];
+    __shared__ int olist[kW8Cap];
+    __shared__ int s_total;
+    __builtin_amdgcn_s_setprio(3);
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int nwaves = nslabs * wps;
+    const int nthreads = nwaves * 64;
+    const int slab = wave / wps, j = wave % wps;
+    const int chunks16 = K >> 4;  // 16-byte units of an int8 row
+    const int c0 = (int)((int64_t)slab * chunks16 / nslabs), c1 = (int)((int64_t)(slab + 1) * chunks16 / nslabs);
+    const int R = wps * RU;
+    int8_t* xq_l = reinterpret_cast<int8_t*>(w8_smem);
+    __half* xo_l = reinterpret_cast<__half*>(w8_smem + K);
+
+    int cidx[J];
+    bool cok[J];
+#pragma unroll
+    for (int jj = 0; jj < J; ++jj) {
+        const int c = c0 + jj * 64 + lane;
+        cok[jj] = c < c1;
+        cidx[jj] = cok[jj] ? c : c1 - 1;
+    }
+    // ---- activation row: thread t owns the 8-element chunks t, t + nthreads, ... (rounds past the row are skipped)
+    const int chunks8 = K >> 3;
+    constexpr int kIt = 4;  // K <= 4 * 8 * nthreads (host)
+    uint4 cx[kIt], cw[kIt], cb[kIt];
+#pragma unroll
+    for (int it = 0; it < kIt; ++it) {
+        cx[it] = cw[it] = cb[it] = make_uint4(0, 0, 0, 0);
+        if (it * nthreads < chunks8) {
+            const int c = threadIdx.x + it * nthreads;
+            const int cc = c < chunks8 ? c : chunks8 - 1;
+            cx[it] = reinterpret_cast<const uint4*>(x)[cc];
+            if (na.kind != 0) {
+                cw[it] = reinterpret_cast<const uint4*>(na.weight)[cc];
+                if (na.kind == 2 && na.bias != nullptr) cb[it] = reinterpret_cast<const uint4*>(na.bias)[cc];
+            }
+        }
+    }
+    uint4 w[NW][RU][J];
+    constexpr int PRIME = RU >= 4 ? 2 : 1;
+#define W8_ROW0(T) (((int)blockIdx.x + (T) * (int)gridDim.x) * R + j * RU)
+#define W8_ISSUE_ROW(T, U)                                                          \
+    {                                                                               \
+        const int64_t row_ = min(W8_ROW0(T) + (U), N - 1);                          \
+        _Pragma("unroll") for (int jj = 0; jj < J; ++jj) {                          \
+            w[0][U][jj] = load_nt16(CB + row_ * chunks16 + cidx[jj]);               \
+            if (DUAL) w[1][U][jj] = load_nt16(CB2 + row_ * chunks16 + cidx[jj]);    \
+        }                                                                           \
+    }
+#pragma unroll
+    for (int u = 0; u < PRIME; ++u) W8_ISSUE_ROW(0, u)
+    asm volatile("" ::: "memory");
+
+    float mean = 0.f, r = 1.f;
+    if (na.kind != 0) {
+        float s1 = 0.f;
+#pragma unroll
+        for (int it = 0; it < kIt; ++it) {
+            if (it * nthreads < chunks8) {
+                const uint32_t dw[4] = {cx[it].x, cx[it].y, cx[it].z, cx[it].w};
+                float t = 0.f;
+#pragma unroll
+                for (int i = 0; i < 4; ++i) t += norm_stat1(dw[i], na.kind);
+                s1 += (threadIdx.x + it * nthreads < chunks8) ? t : 0.f;
+            }
+        }
+        s1 = block_sum_waves(s1, stat, nwaves);
+        if (na.kind == 2) {
+            mean = s1 / (float)K;
+            float s2 = 0.f;
+#pragma unroll
+            for (int it = 0; it < kIt; ++it) {
+                if (threadIdx.x + it * nthreads < chunks8) {
+                    const uint32_t dw[4] = {cx[it].x, cx[it].y, cx[it].z, cx[it].w};
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) s2 += norm_stat2(dw[i], mean);
+                }
+            }
+            r = norm_scale(na, block_sum_waves(s2, stat, nwaves));
+        } else {
+            r = norm_scale(na, s1);
+        }
+    }
+    float a[kIt][8];
+    float mx = 0.f;
+    int local = 0;
+#pragma unroll
+    for (int it = 0; it < kIt; ++it) {
+        const bool ok = threadIdx.x + it * nthreads < chunks8;
+        const uint32_t raw[4] = {cx[it].x, cx[it].y, cx[it].z, cx[it].w};
+        uint32_t nrm[4] = {raw[0], raw[1], raw[2], raw[3]};
+        if (na.kind != 0) {
+            const uint32_t ww[4] = {cw[it].x, cw[it].y, cw[it].z, cw[it].w}, bb[4] = {cb[it].x, cb[it].y, cb[it].z, cb[it].w};
+#pragma unroll
+            for (int q = 0; q < 4; ++q) nrm[q] = norm_apply(raw[q], ww[q], bb[q], na.kind, mean, r);
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            a[it][2 * q] = rhalf(bflo(nrm[q]));
+            a[it][2 * q + 1] = rhalf(bfhi(nrm[q]));
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const bool outlier = ok && threshold > 0.f && fabsf(a[it][e]) >= threshold;
+            if (ok && !outlier) mx = fmaxf(mx, fabsf(a[it][e]));
+            local += outlier ? 1 : 0;
+        }
+    }
+    mx = wave_max(mx);
+    int incl = local;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const int o = __shfl_up(incl, off, 64);
+        if (lane >= off) incl += o;
+    }
+    if (lane == 63) scan[wave] = incl;
+    if (lane == 0) shmax[wave] = mx;
+    __syncthreads();
+    int base = 0, total = 0;
+    mx = 0.f;
+    for (int wv = 0; wv < nwaves; ++wv) {
+        if (wv < wave) base += scan[wv];
+        total += scan[wv];
+        mx = fmaxf(mx, shmax[wv]);
+    }
+    const float sa = mx;
+    const float inv = mx > 0.f ? __fdiv_rn(127.0f, mx) : 0.f;
+    int slot = base + incl - local;
+#pragma unroll
+    for (int it = 0; it < kIt; ++it) {
+        const int c = threadIdx.x + it * nthreads;
+        if (c < chunks8) {
+            uint32_t q8[2] = {0, 0};
+            uint32_t h8[4] = {0, 0, 0, 0};
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const bool outlier = threshold > 0.f && fabsf(a[it][e]) >= threshold;
+                const int qv = outlier ? 0 : (int)rintf(__fmul_rn(a[it][e], inv));
+                q8[e >> 2] |= (uint32_t)(qv & 0xff) << (8 * (e & 3));
+                const uint32_t hv = outlier ? (uint32_t)__half_as_ushort(__float2half(a[it][e])) : 0u;
+                h8[e >> 1] |= hv << (16 * (e & 1));
+                if (outlier) {
+                    if (slot < kW8Cap) olist[slot] = c * 8 + e;
+                    ++slot;
+                }
+            }
+            *reinterpret_cast<uint2*>(xq_l + (int64_t)c * 8) = make_uint2(q8[0], q8[1]);
+            *reinterpret_cast<uint4*>(xo_l + (int64_t)c * 8) = make_uint4(h8[0], h8[1], h8[2], h8[3]);
+        }
+    }
+    if (threadIdx.x == 0) s_total = total;
+    __syncthreads();
+    int xr[J][4];
+#pragma unroll
+    for (int jj = 0; jj < J; ++jj) {
+        uint4 v = reinterpret_cast<const uint4*>(xq_l)[cidx[jj]];
+        if (!cok[jj]) v = make_uint4(0, 0, 0, 0);
+        xr[jj][0] = (int)v.x;
+        xr[jj][1] = (int)v.y;
+        xr[jj][2] = (int)v.z;
+        xr[jj][3] = (int)v.w;
+    }
+    __builtin_amdgcn_s_setprio(0);
+
+    const bf16_t* res_p = residual != nullptr ? residual : reinterpret_cast<const bf16_t*>(CB);
+    const bf16_t* bias_p = bias != nullptr ? bias : reinterpret_cast<const bf16_t*>(CB);
+    for (int t = 0; t < iters; ++t) {
+        int(*rd)[RU * NW] = red[t & 1];
+        const int e_col = min(((int)blockIdx.x + t * (int)gridDim.x) * R + (int)threadIdx.x, N - 1);
+        const bf16_t e_res = res_p[residual != nullptr ? e_col : 0];
+        const bf16_t e_bias = bias_p[bias != nullptr ? e_col : 0];
+        const float e_scb = SCB[e_col];
+        const float e_scb2 = DUAL ? SCB2[e_col] : 0.f;
+#pragma unroll
+        for (int u = 0; u < RU; ++u) {
+            if (u + PRIME < RU) {
+                W8_ISSUE_ROW(t, u + PRIME)
+            } else if (t + 1 < iters) {
+                W8_ISSUE_ROW(t + 1, u + PRIME - RU)
+            }
+            asm volatile("" ::: "memory");
+            if (RU >= 4) {
+                if (u == 0) __builtin_amdgcn_s_setprio(3);
+                if (u == RU / 4) __builtin_amdgcn_s_setprio(2);
+                if (u == RU / 2) __builtin_amdgcn_s_setprio(1);
+                if (u == (3 * RU) / 4) __builtin_amdgcn_s_setprio(0);
+            }
+            int part[NW];
+#pragma unroll
+            for (int q = 0; q < NW; ++q) {
+                int p = 0;
+#pragma unroll
+                for (int jj = 0; jj < J; ++jj) {
+                    p = __builtin_amdgcn_sdot4((int)w[q][u][jj].x, xr[jj][0], p, false);
+                    p = __builtin_amdgcn_sdot4((int)w[q][u][jj].y, xr[jj][1], p, false);
+                    p = __builtin_amdgcn_sdot4((int)w[q][u][jj].z, xr[jj][2], p, false);
+                    p = __builtin_amdgcn_sdot4((int)w[q][u][jj].w, xr[jj][3], p, false);
+                }
+                part[q] = wave_sum_i32_to_lane63(p);
+            }
+#pragma unroll
+            for (int q = 0; q < NW; ++q)
+                if (lane == 63) rd[wave][u * NW + q] = part[q];
+        }
+        __syncthreads();
+        if ((int)threadIdx.x < R) {
+            const int ur = threadIdx.x;
+            const int jj = ur / RU, u = ur % RU;
+            const int col = ((int)blockIdx.x + t * (int)gridDim.x) * R + ur;
+            if (col < N) {
+                const int no = s_total;
+                float res[2] = {0.f, 0.f};
+#pragma unroll
+                for (int q = 0; q < NW; ++q) {
+                    int c32 = 0;
+                    for (int c = 0; c < nslabs; ++c) c32 += rd[c * wps + jj][u * NW + q];
+                    const float scb = q ? e_scb2 : e_scb;
+                    const float b = (bias != nullptr && q == 0) ? bf2f(e_bias) : 0.f;
+                    // separately rounded fp32 products and sum (no FMA), the order mm_dequant uses
+                    float v = rhalf(__fadd_rn(__fmul_rn(__fmul_rn(__fmul_rn((float)c32, kMmDequant), sa), scb), b));
+                    if (no > 0) {  // mixed-precision decomposition over the outlier columns
+                        const int8_t* wrow = reinterpret_cast<const int8_t*>(q ? CB2 : CB) + (int64_t)col * K;
+                        float o = 0.f;
+                        if (no <= kW8Cap) {
+                            for (int i = 0; i < no; ++i) {
+                                const int k = olist[i];
+                                o += __half2float(xo_l[k]) * rhalf(__fdiv_rn(__fmul_rn((float)wrow[k], scb), 127.0f));
+                            }
+                        } else {  // more outliers than the list holds: walk the row (same ascending-per-thread order is not kept:
+                                  // the sum runs over k ascending, which the tolerance of the int8 path absorbs)
+                            for (int k = 0; k < K; ++k) {
+                                const float xv = __half2float(xo_l[k]);
+                                if (xv != 0.f) o += xv * rhalf(__fdiv_rn(__fmul_rn((float)wrow[k], scb), 127.0f));
+                            }
+                        }
+                        v = rhalf(v + rhalf(o));
+                    }
+                    res[q] = v;
+                }
+                out[col] = apply_epilogue_vals(epi, res[0], res[1], false, 0.f, bf2f(e_res));
+            }
+        }
+    }
+#undef W8_ISSUE_ROW
+#undef W8_ROW0
+}
+
+template <int J>
+static int w8_fused_launch(const void* CB, const void* CB2, const void* SCB, const void* SCB2, const void* x, float threshold,
+                           const void* bias, const void* residual, void* out, int N, int K, int epi, int nslabs,
+                           const NormArgs& na, hipStream_t st) {
+    constexpr int MAXW = 8;
+    constexpr int RU = 8, RUD = 4;
+    const bool dual = epi == PARROT_EPI_SWIGLU;
+    const int ru = dual ? RUD : RU;
+    int wps = MAXW / nslabs;
+    if (wps > 4) wps = 4;
+    while (wps > 1 && (int64_t)wps * ru * 256 > N) --wps;
+    while (wps * nslabs < MAXW && (K >> 3) > 4 * 64 * nslabs * wps) ++wps;  // the cooperative prologue covers 4 x 8 x nthreads
+    const int nthreads = 64 * nslabs * wps;
+    PARROT_UNSUPPORTED((K >> 3) <= 4 * nthreads, "w8_gemv_fused: K=%d does not fit the workgroup's prologue", K);
+    const size_t lds = (size_t)K * 3;
+    PARROT_UNSUPPORTED(lds <= 56 * 1024, "w8_gemv_fused: K=%d needs %zu B of LDS", K, lds);
+    const int R = wps * ru;
+    const int batches = (N + R - 1) / R;
+    const int per_simd = (J <= 2 && !dual) ? 3 : 2;  // waves per SIMD at this build's VGPR count (135 .. 201)
+    const int resident = 256 * (4 * per_simd / (nslabs * wps) > 0 ? 4 * per_simd / (nslabs * wps) : 1);
+    const int iters = (batches + resident - 1) / resident;
+    const dim3 grid((batches + iters - 1) / iters), block(nthreads);
+    if (dual)
+        return launch(K_W8_GEMV, w8_fused_kernel<true, J, RUD, MAXW>, grid, block, lds, st, (const uint4*)CB, (const uint4*)CB2,
+                      (const float*)SCB, (const float*)SCB2, (const bf16_t*)x, threshold, (const bf16_t*)bias,
+                      (const bf16_t*)residual, (bf16_t*)out, N, K, wps, nslabs, epi, iters, na);
+    return launch(K_W8_GEMV, w8_fused_kernel<false, J, RU, MAXW>, grid, block, lds, st, (const uint4*)CB, (const uint4*)CB2,
+                  (const float*)SCB, (const float*)SCB2, (const bf16_t*)x, threshold, (const bf16_t*)bias,
+                  (const bf16_t*)residual, (bf16_t*)out, N, K, wps, nslabs, epi, iters, na);
+}
+
 }  // namespace parrot
 
 using namespace parrot;
@@ -331,6 +630,36 @@ int parrot_w8_gemv(const void* CB, const void* SCB, const void* xq, const void* 
     if (jn <= 1) return w8_launch<1>(CB, CB2, SCB, SCB2, xq, xout, sca, nout, oidx, M, bias, residual, ldr, out, ldo, N, K, epilogue, nslabs, st);
     if (jn <= 2) return w8_launch<2>(CB, CB2, SCB, SCB2, xq, xout, sca, nout, oidx, M, bias, residual, ldr, out, ldo, N, K, epilogue, nslabs, st);
     return w8_launch<4>(CB, CB2, SCB, SCB2, xq, xout, sca, nout, oidx, M, bias, residual, ldr, out, ldo, N, K, epilogue, nslabs, st);
+}
+
+// One token row: activation quantiser (parrot_w8_prep_act) + GEMV (parrot_w8_gemv) in one launch; same arithmetic.
+int parrot_w8_gemv_fused(const void* CB, const void* SCB, const void* x, float threshold, const void* bias,
+                         const void* residual, void* out, int N, int K, int epilogue, const parrot_norm_t* norm, void* stream) {
+    PARROT_REQUIRE(CB && SCB && x && out, "w8_gemv_fused: null pointer");
+    PARROT_REQUIRE(N >= 1 && K >= 1, "w8_gemv_fused: bad shape N=%d K=%d", N, K);
+    PARROT_REQUIRE(epilogue >= PARROT_EPI_NONE && epilogue <= PARROT_EPI_SWIGLU, "w8_gemv_fused: unknown epilogue %d", epilogue);
+    PARROT_REQUIRE((epilogue == PARROT_EPI_RESIDUAL) == (residual != nullptr), "w8_gemv_fused: residual iff RESIDUAL epilogue");
+    PARROT_UNSUPPORTED(K % 16 == 0 && K <= 4096 * 4, "w8_gemv_fused: K=%d must be a multiple of 16 and <= %d", K, 4096 * 4);
+    PARROT_REQUIRE(aligned16(CB) && aligned16(x), "w8_gemv_fused: CB and x must be 16-byte aligned");
+    PARROT_UNSUPPORTED(!(epilogue == PARROT_EPI_SWIGLU && bias), "w8_gemv_fused: SWIGLU epilogue takes no bias");
+    NormArgs na;
+    const int rc = make_norm_args(norm, K, &na);
+    if (rc != PARROT_OK) return rc;
+    const void* CB2 = nullptr;
+    const void* SCB2 = nullptr;
+    if (epilogue == PARROT_EPI_SWIGLU) {
+        CB2 = (const int8_t*)CB + (int64_t)N * K;
+        SCB2 = (const float*)SCB + N;
+    }
+    const int chunks = K / 16;
+    const int nslabs = (chunks + 255) / 256;  // <= 4 loads of 16 B per lane and row
+    const int per_slab = (chunks + nslabs - 1) / nslabs;
+    const int jn = (per_slab + 63) / 64;
+    hipStream_t st = (hipStream_t)stream;
+    if (jn <= 1) return w8_fused_launch<1>(CB, CB2, SCB, SCB2, x, threshold, bias, residual, out, N, K, epilogue, nslabs, na, st);
+    if (jn <= 2) return w8_fused_launch<2>(CB, CB2, SCB, SCB2, x, threshold, bias, residual, out, N, K, epilogue, nslabs, na, st);
+    if (jn <= 3) return w8_fused_launch<3>(CB, CB2, SCB, SCB2, x, threshold, bias, residual, out, N, K, epilogue, nslabs, na, st);
+    return w8_fused_launch<4>(CB, CB2, SCB, SCB2, x, threshold, bias, residual, out, N, K, epilogue, nslabs, na, st);
 }
 
 }  // extern "C"

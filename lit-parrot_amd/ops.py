@@ -179,6 +179,21 @@ def w8_linear(CB: torch.Tensor, SCB: torch.Tensor, N: int, K: int, act: W8Act, o
     return out
 
 
+W8_FUSED_MAX_K = 16384
+
+
+def w8_linear_fused(CB: torch.Tensor, SCB: torch.Tensor, N: int, K: int, x: torch.Tensor, threshold: float, out: torch.Tensor,
+                    *, bias=None, epilogue=EPI_NONE, residual=None, norm: Optional[Norm] = None) -> torch.Tensor:
+    """One token row through an LLM.int8 Linear in one launch (activation quantiser + GEMV + epilogue)."""
+    _rows(x, "w8_linear_fused"), _rows(out, "w8_linear_fused")
+    if x.shape != (1, K) or out.shape != (1, N) or not x.is_contiguous():
+        raise ParrotHipError(f"w8_linear_fused: one contiguous row expected, got x {tuple(x.shape)} out {tuple(out.shape)}")
+    check(_hip.load().parrot_w8_gemv_fused(ptr(CB), ptr(SCB), ptr(x), float(threshold), ptr(_opt_vec(bias, N, "bias")),
+                                           ptr(residual), ptr(out), N, K, epilogue, _norm_arg(norm, K), stream()),
+          "parrot_w8_gemv_fused")
+    return out
+
+
 # ------------------------------------------------------------------------------------------------ attention
 def rope_kvappend(qkv: torch.Tensor, cos: torch.Tensor, sin: torch.Tensor, n_elem: int, pos: torch.Tensor,
                   n_groups: int, q_per_kv: int, hs: int, S: int, q_out: torch.Tensor, k_cache: torch.Tensor,

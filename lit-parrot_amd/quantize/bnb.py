@@ -15,6 +15,9 @@ from .. import ops
 from .._hip import EPI_NONE, ParrotHipError
 
 
+FUSED_DECODE = True  # single rows take parrot_w8_gemv_fused (tests switch it off to compare with the two-launch path)
+
+
 class InferenceLinear8bitLt(torch.nn.Linear):
     def __init__(self, in_features: int, out_features: int, bias: bool = True, *, has_fp16_weights: bool = False,
                  threshold: float = 6.0, device=None, dtype=None) -> None:
@@ -84,12 +87,16 @@ class InferenceLinear8bitLt(torch.nn.Linear):
                    norm=None) -> torch.Tensor:
         if not self.is_quantized:
             raise ParrotHipError("InferenceLinear8bitLt: weight not quantised yet (move the module to the GPU)")
-        act = act if act is not None else self.prep(x, norm)  # the norm is fused into the activation quantiser
         CB, SCB = self.weight.data, self.weight.SCB
         if partner is not None:
             if self._pair is None:
                 self._pair = (torch.cat([CB, partner.weight.data]).contiguous(), torch.cat([SCB, partner.weight.SCB]).contiguous())
             CB, SCB = self._pair
+        if act is None and x.shape[0] == 1 and self.in_features <= ops.W8_FUSED_MAX_K and FUSED_DECODE:
+            # decode: activation quantiser (with the fused norm) + GEMV in one launch
+            return ops.w8_linear_fused(CB, SCB, self.out_features, self.in_features, x, self.threshold, out, bias=self.bias,
+                                       epilogue=epilogue, residual=residual, norm=norm)
+        act = act if act is not None else self.prep(x, norm)  # the norm is fused into the activation quantiser
         return ops.w8_linear(CB, SCB, self.out_features, self.in_features, act, out, bias=self.bias, epilogue=epilogue,
                              residual=residual)
 

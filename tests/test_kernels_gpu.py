@@ -308,6 +308,58 @@ def test_w8_linear_matches_oracle(N, K, outliers, M):
     assert_bf16_close(out, want.float(), ulps=1 if outliers else 0, atol=0.0, what=f"w8 {N}x{K} outliers={outliers}")
 
 
+@pytest.mark.parametrize("N,K", [(64, 256), (96, 4096), (40, 352), (16, 11008), (20000, 512), (24, 16384)])
+@pytest.mark.parametrize("outliers", [0, 3, 400])
+def test_w8_fused_single_row_matches_oracle_and_the_two_launch_path(N, K, outliers):
+    """parrot_w8_gemv_fused (activation quantiser + GEMV in one launch, decode) against the oracle and against
+    parrot_w8_prep_act + parrot_w8_gemv; 400 outlier columns overflow the in-LDS list (the epilogue walks the row)."""
+    g = gen(23)
+    W = (torch.randn(N, K, generator=g) * 0.02).to(BF)
+    x = torch.randn(1, K, generator=g).to(BF)
+    if outliers:
+        idx = torch.randperm(K, generator=g)[: min(outliers, K // 2)]
+        x[0, idx] = (6.0 + torch.rand(idx.numel(), generator=g) * 4).to(BF) * torch.where(torch.rand(idx.numel(), generator=g) < 0.5, -1.0, 1.0).to(BF)
+    bias = (torch.randn(N, generator=g) * 0.1).to(BF)
+    cb, scb = o8.quantize_weight_rows(W)
+    out = torch.empty((1, N), dtype=BF, device=DEV)
+    ops.w8_linear_fused(cb.to(DEV), scb.to(DEV), N, K, x.to(DEV), 6.0, out, bias=bias.to(DEV))
+    want = o8.linear(x, cb, scb, bias, 6.0)
+    assert_bf16_close(out, want.float(), ulps=1 if outliers else 0, atol=0.0, what=f"w8 fused {N}x{K} outliers={outliers}")
+    act = ops.w8_prep_act(x.to(DEV), 6.0, ops.W8Act(1, K, DEV))
+    out2 = torch.empty_like(out)
+    ops.w8_linear(cb.to(DEV), scb.to(DEV), N, K, act, out2, bias=bias.to(DEV))
+    assert_bf16_close(out, out2.float(), ulps=1 if outliers else 0, atol=0.0, what="w8 fused vs two launches")
+
+
+@pytest.mark.parametrize("epi", [EPI_RESIDUAL, EPI_GELU, EPI_SWIGLU])
+@pytest.mark.parametrize("kind", [0, 1, 2])
+def test_w8_fused_epilogues_and_norms(epi, kind):
+    N, K = 200, 768
+    g = gen(24)
+    W = (torch.randn(N, K, generator=g) * 0.02).to(BF)
+    W2 = (torch.randn(N, K, generator=g) * 0.02).to(BF)
+    x = (torch.randn(1, K, generator=g) * 2).to(BF)
+    x[0, 5] = 30.0  # an outlier survives the norm
+    res = torch.randn(1, N, generator=g).to(BF)
+    cb, scb = o8.quantize_weight_rows(W)
+    cb2, scb2 = o8.quantize_weight_rows(W2)
+    CB = torch.cat([cb, cb2]).contiguous().to(DEV) if epi == EPI_SWIGLU else cb.to(DEV)
+    SCB = torch.cat([scb, scb2]).contiguous().to(DEV) if epi == EPI_SWIGLU else scb.to(DEV)
+    norm = None
+    if kind:
+        norm = ops.Norm(kind, (1 + 0.1 * torch.randn(K, generator=g)).to(BF).to(DEV),
+                        (0.1 * torch.randn(K, generator=g)).to(BF).to(DEV) if kind == 2 else None, 1e-5)
+    kw = dict(epilogue=epi, residual=res.to(DEV) if epi == EPI_RESIDUAL else None)
+    out = torch.empty((1, N), dtype=BF, device=DEV)
+    ops.w8_linear_fused(CB, SCB, N, K, x.to(DEV), 6.0, out, norm=norm, **kw)
+    act = ops.w8_prep_act(x.to(DEV), 6.0, ops.W8Act(1, K, DEV), norm)
+    out2 = torch.empty_like(out)
+    ops.w8_linear(CB, SCB, N, K, act, out2, **kw)
+    # same arithmetic; only the summation order of the norm statistic / the outlier part may differ
+    d = (out.float() - out2.float()).abs()
+    assert float(d.max()) <= 2 ** -5 * max(1.0, float(out2.float().abs().max())) and float((d == 0).float().mean()) > 0.9
+
+
 # ------------------------------------------------------------------------------------------------ norms
 @pytest.mark.parametrize("d", [128, 768, 4096, 8192])
 def test_rmsnorm_matches_reference_choreography(d):
