@@ -639,6 +639,9 @@ static int w4_gemv_launch(const void* packed, const void* packed2, const void* x
     return w4_gemv_launch_v<M, DUALV, RUV, MAXWV>(packed, packed2, x, ldx, bias, residual, ldr, out, ldo, N, K, epi, na, plan, st)
     if (plan.nslabs <= 8) {
         if (epi == PARROT_EPI_SWIGLU) PARROT_W4_GO(true, RU2, 8);
+        // small single-row launches (the attention out-projection: N x slabs <= 16 K): 4 rows per wave, twice the waves -
+        // measured +1 % end to end; for the MLP down-projection (N = 4096 but 6 slabs) the same change costs 2.5 %
+        if (M == 1 && (int64_t)N * plan.nslabs <= 8192 * 2) PARROT_W4_GO(false, 4, 8);
         PARROT_W4_GO(false, RU1, 8);
     }
     if (epi == PARROT_EPI_SWIGLU) PARROT_W4_GO(true, 2, 16);
