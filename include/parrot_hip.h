@@ -165,6 +165,13 @@ int parrot_embedding(const void* wte, int d, const int64_t* tokens, const int32_
 int parrot_prefetch(const void* data, int64_t bytes, int workgroups, void* stream);
 /* greedy step of generate() (generate/base.py:136-153 with top_k=1):
  * tokens[*pos + 1] = argmax(logits) (lowest index on ties); then *pos += 1.          */
+/* Chat loop (chat/base.py:80-87): after a sampling step wrote tokens[*pos], latch the first stop sequence that the generated
+ * tokens end with.  stop_flat: the sequences back to back (int64), stop_off: n_stop + 1 offsets, longest: the longest
+ * sequence (the reference's look-back buffer: nothing matches before `longest` tokens were generated), first_gen: device
+ * int32, index of the first generated token.  flag: int32[2], {-1, 0} before; {generated-token number of the hit, length
+ * of the matched sequence} after.                                                                                      */
+int parrot_stop_check(const int64_t* tokens, const int32_t* pos, const int32_t* first_gen, const int64_t* stop_flat,
+                      const int32_t* stop_off, int n_stop, int longest, int32_t* flag, void* stream);
 int parrot_argmax_advance(const void* logits, int V, int64_t* tokens, int32_t* pos, void* stream);
 
 /* ---- persistent decode step: ONE launch per token --------------------------------------------------

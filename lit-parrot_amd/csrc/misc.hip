@@ -88,6 +88,34 @@ argmax_advance_kernel(const bf16_t* __restrict__ logits, int V, int vec, int64_t
     }
 }
 
+// Device-side stop-sequence check of the chat loop (chat/base.py:80-87 restated on the token buffer): after the sampling
+// step has written tokens[pos] (generated token number t = pos - first_gen), a stop sequence of n tokens matches iff
+// t >= L - 1 (L = longest stop sequence: the reference's look-back buffer is still filling before that and its tail holds
+// the filler) and tokens[pos-n+1 .. pos] equals it; sequences are tried in list order, the first hit is latched:
+// flag[0] = t of the hit (-1: none so far), flag[1] = n.  One wave; the host reads the flag every few tokens instead of
+// comparing on the host after every token.
+__global__ void __launch_bounds__(64)
+stop_check_kernel(const int64_t* __restrict__ tokens, const int32_t* __restrict__ pos_ptr, const int32_t* __restrict__ first_gen,
+                  const int64_t* __restrict__ stop_flat, const int32_t* __restrict__ stop_off, int n_stop, int L,
+                  int32_t* __restrict__ flag) {
+    if (flag[0] >= 0) return;  // latched
+    const int pos = pos_ptr[0];
+    const int t = pos - first_gen[0];
+    if (t < L - 1) return;
+    for (int s = 0; s < n_stop; ++s) {
+        const int o = stop_off[s], n = stop_off[s + 1] - o;
+        bool eq = true;
+        for (int i = threadIdx.x; i < n; i += 64) eq = eq && (tokens[pos - n + 1 + i] == stop_flat[o + i]);
+        if (__all(eq)) {  // uniform
+            if (threadIdx.x == 0) {
+                flag[0] = t;
+                flag[1] = n;
+            }
+            return;
+        }
+    }
+}
+
 // Touch a read-only buffer so that its lines are on chip (Infinity Cache / L2) when the kernel that needs them starts.
 // Launched on a side stream next to the kernel that precedes the consumer: it keeps the HBM busy during that kernel's
 // dispatch, arithmetic and tail phases.  Pure prefetch: nothing depends on it and it writes nothing (the conditional
@@ -129,6 +157,15 @@ int parrot_prefetch(const void* data, int64_t bytes, int workgroups, void* strea
     if (workgroups > 4096) workgroups = 4096;
     return launch(K_PREFETCH, prefetch_kernel, dim3(workgroups), dim3(256), 0, (hipStream_t)stream, (const uint4*)data,
                   bytes / 16, (unsigned int*)nullptr);
+}
+
+int parrot_stop_check(const int64_t* tokens, const int32_t* pos, const int32_t* first_gen, const int64_t* stop_flat,
+                      const int32_t* stop_off, int n_stop, int longest, int32_t* flag, void* stream) {
+    PARROT_REQUIRE(tokens && pos && first_gen && flag, "stop_check: null pointer");
+    PARROT_REQUIRE(n_stop >= 0 && longest >= 1, "stop_check: bad arguments n_stop=%d longest=%d", n_stop, longest);
+    PARROT_REQUIRE(n_stop == 0 || (stop_flat && stop_off), "stop_check: stop sequences missing");
+    return launch(K_STOP_CHECK, stop_check_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, tokens, pos, first_gen, stop_flat,
+                  stop_off, n_stop, longest, flag);
 }
 
 int parrot_argmax_advance(const void* logits, int V, int64_t* tokens, int32_t* pos, void* stream) {

@@ -67,6 +67,7 @@ enum KernelId : int {
     K_ATTN_FUSED,
     K_PK_TOKEN,
     K_PREFETCH,
+    K_STOP_CHECK,
     K_COUNT
 };
 

@@ -270,6 +270,15 @@ def argmax_advance(logits: torch.Tensor, tokens: torch.Tensor, pos: torch.Tensor
           "parrot_argmax_advance")
 
 
+def stop_check(tokens: torch.Tensor, pos: torch.Tensor, first_gen: torch.Tensor, stop_flat: torch.Tensor,
+               stop_off: torch.Tensor, n_stop: int, longest: int, flag: torch.Tensor) -> None:
+    """Latch in ``flag`` (int32[2]) the first stop sequence that the generated tokens end with (chat loop)."""
+    if tokens.dtype != torch.int64 or stop_flat.dtype != torch.int64 or any(t.dtype != torch.int32 for t in (pos, first_gen, stop_off, flag)):
+        raise ParrotHipError("stop_check: tokens / stop_flat int64; pos, first_gen, stop_off, flag int32")
+    check(_hip.load().parrot_stop_check(ptr(tokens), ptr(pos), ptr(first_gen), ptr(stop_flat), ptr(stop_off), n_stop, longest,
+                                        ptr(flag), stream()), "parrot_stop_check")
+
+
 def prefetch(t: torch.Tensor, workgroups: int = 256, nbytes: Optional[int] = None) -> None:
     """Enqueue (on the current stream) a read of ``t`` that leaves its lines in the on-chip caches."""
     n = t.numel() * t.element_size() if nbytes is None else min(nbytes, t.numel() * t.element_size())

@@ -225,9 +225,57 @@ def golden_generate(ref):
     print("generate", y[128:].tolist()[:8], "... eos stops at", len(y2), "first idx", first)
 
 
+@torch.no_grad()
+def golden_chat(ref):
+    """chat/base.py::generate (the streaming generator with multi-token stop sequences) on a tiny fp32 model, greedy.
+    Stored: for every case the stop sequences and the list of yielded items (each item flattened to a list of ints)."""
+    import chat.base as chat_base
+    from lit_parrot_amd.config import name_to_config, Config
+    from lit_parrot_amd.synth import synthetic_prompt, synthetic_state_dict
+
+    cfg_dict = dict(name_to_config["tiny-llama"])
+    tiny = Config(**cfg_dict)
+    sd = synthetic_state_dict(tiny, MODEL_SEED, perturb=True)
+    model = ref_model(ref, cfg_dict, sd, torch.float32)
+    p = synthetic_prompt(tiny, 6, MODEL_SEED)
+    MAXR = 40
+
+    def run(stop):
+        model.reset_cache()
+        torch.manual_seed(1234)
+        items = []
+        for y in chat_base.generate(model, p, MAXR, max_seq_length=MAXR, temperature=1.0, top_k=1, stop_tokens=stop):
+            items.append([int(v) for v in y.reshape(-1).tolist()])
+        return items
+
+    free = [it[0] for it in run(())]  # no stop sequence: one token per yield
+    assert len(free) == MAXR - 6
+    cases = {
+        "none": (),
+        "single": ([free[9]],),                                        # the 10th generated token, as a 1-token stop
+        "pair": ([free[12], free[13]],),                               # a 2-token stop sequence
+        "pair_and_long": ([free[20], free[21]], [1, 2, 3, 4]),         # buffer of 4, the 2-token one hits: leftovers are yielded
+        "early": ([free[0], free[1]], [free[5], free[6], free[7]]),    # hit while the buffer is still filling
+        "never": ([499, 498, 497],),                                   # never matches: the tail of the buffer is never yielded
+    }
+    out = {"prompt": p.numpy(), "max_returned": np.array(MAXR), "free": np.array(free)}
+    for name, stop in cases.items():
+        items = run(stop)
+        out[f"{name}_stop_flat"] = np.array([t for sq in stop for t in sq] or [-1])
+        out[f"{name}_stop_lens"] = np.array([len(sq) for sq in stop] or [0])
+        out[f"{name}_items_flat"] = np.array([t for it in items for t in it] or [-1])
+        out[f"{name}_items_lens"] = np.array([len(it) for it in items] or [0])
+        print("chat", name, "yields", len(items), "items", [len(it) for it in items if len(it) != 1])
+    np.savez_compressed(OUT / "chat.npz", **out)
+
+
 if __name__ == "__main__":
     ref = import_reference()
+    if "--chat-only" in sys.argv:
+        golden_chat(ref)
+        sys.exit(0)
     golden_pieces(ref)
     golden_gptq(ref)
     golden_models(ref)
     golden_generate(ref)
+    golden_chat(ref)

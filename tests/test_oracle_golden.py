@@ -159,3 +159,39 @@ def test_gptq_model_oracle_consistent():
         a = om.OracleGPT(cfg, qsd, "gptq", tile_cols=128)(idx)
         b = om.OracleGPT(cfg, dense)(idx)
     assert torch.equal(a, b)
+
+
+def _chat_case(g, name):
+    lens = [int(v) for v in g[f"{name}_stop_lens"]]
+    flat = [int(v) for v in g[f"{name}_stop_flat"]]
+    stops, o = [], 0
+    for n in lens:
+        if n:
+            stops.append(flat[o:o + n])
+            o += n
+    ilens = [int(v) for v in g[f"{name}_items_lens"]]
+    iflat = [int(v) for v in g[f"{name}_items_flat"]]
+    items, o = [], 0
+    for n in ilens:
+        if n:
+            items.append(iflat[o:o + n])
+            o += n
+    return tuple(stops), items
+
+
+@pytest.mark.parametrize("case", ["none", "single", "pair", "pair_and_long", "early", "never"])
+def test_chat_generator_matches_the_reference_stream(golden_dir, case):
+    """oracle/chat.py against what the reference's chat.base.generate yielded (greedy, tiny-llama fp32): the same items in the
+    same grouping, including the multi-token leftover item on a hit and the never-yielded tail."""
+    from oracle import chat as oc
+
+    g = np.load(golden_dir / "chat.npz")
+    cfg = Config.from_name("tiny-llama")
+    sd = synthetic_state_dict(cfg, MODEL_SEED, perturb=True)
+    model = om.OracleGPT(cfg, sd)
+    stops, want = _chat_case(g, case)
+    torch.manual_seed(1234)
+    got = [[int(v) for v in y.reshape(-1).tolist()]
+           for y in oc.generate(model, torch.from_numpy(g["prompt"]), int(g["max_returned"]), int(g["max_returned"]),
+                                temperature=1.0, top_k=1, stop_tokens=stops)]
+    assert got == want
