@@ -80,8 +80,10 @@ int parrot_w4_gemv(const void* packed, const void* packed2, const void* x, int l
                    int K, int group, int epilogue, const parrot_norm_t* norm, void* stream);
 /* same contract for any M (prefill) on the matrix cores (v_mfma_f32_32x32x16_bf16; the int4 rows are expanded to
  * bf16 in LDS).  M <= 8 forwards to the GEMV.  For M > 8 the norm must already be applied (norm == NULL) and
- * `workspace` holds parrot_gemm_workspace_floats(M, K, group) floats (per-group activation sums).            */
-int64_t parrot_gemm_workspace_floats(int M, int K, int group);
+ * `workspace` holds parrot_gemm_workspace_floats(M, N, K, group, epilogue) floats: the per-group activation sums (int4)
+ * and, for launches with too few tiles to fill the chip (short prompts), the split-K partial results that a second
+ * stage sums in a fixed order.  group = 0 asks for the bf16 GEMM's needs.                                      */
+int64_t parrot_gemm_workspace_floats(int M, int N, int K, int group, int epilogue);
 int parrot_w4_gemm(const void* packed, const void* packed2, const void* x, int ldx, int M,
                    const void* bias, const void* residual, int ldr, void* out, int ldo, int N,
                    int K, int group, int epilogue, const parrot_norm_t* norm, void* workspace,
@@ -94,7 +96,7 @@ int parrot_bf16_gemv(const void* W, const void* W2, const void* x, int ldx, int 
                      const parrot_norm_t* norm, void* stream);
 int parrot_bf16_gemm(const void* W, const void* W2, const void* x, int ldx, int M, const void* bias,
                      const void* residual, int ldr, void* out, int ldo, int N, int K, int epilogue,
-                     const parrot_norm_t* norm, void* stream);
+                     const parrot_norm_t* norm, void* workspace, void* stream);
 
 /* ---- LLM.int8 (quantize/bnb.py:18-60; arithmetic = bitsandbytes MatMul8bitLt) ----
  * quantize rows of a bf16/fp16-valued weight: CB = rne(127*W/absmax_row), SCB = absmax_row (fp32) */

@@ -14,6 +14,8 @@
 // bf16 operand; at every quantisation-group boundary the group's partial product is folded into the result with the
 // group's scale / zero and the row's activation sum:  acc += scale * (partial - (128 + zero) * sum_g(x)).  These are
 // the numerics of the decode GEMV (w4.hip), so prefill and decode agree.  sum_g(x) comes from a small pre-pass.
+#include <stdlib.h>
+
 #include "parrot_common.h"
 #include "w4_plan.h"
 
@@ -41,11 +43,14 @@ gemm_xsum_kernel(const bf16_t* __restrict__ x, int ldx, int M, int K, int G, int
     xsum[t] = s;
 }
 
-template <bool W4, int GBM, int GBN>
+// SPLIT = the split-K instantiation (raw fp32 partials out, no epilogue); kept apart from the one-pass kernel so that the
+// latter's register allocation is not disturbed (as a run-time switch it cost the bf16 kernel 56 more VGPRs and 30 %).
+template <bool W4, int GBM, int GBN, bool SPLIT>
 __global__ void __launch_bounds__(256)
 gemm_kernel(const bf16_t* __restrict__ A, int lda, int M, const void* __restrict__ Wv, const void* __restrict__ W2v, int N,
             int K, const float* __restrict__ xsum, const bf16_t* __restrict__ bias, const bf16_t* residual, int ldr,
-            bf16_t* out, int ldo, int epi, int xs_lds, W4Plan plan) {
+            bf16_t* out, int ldo, int epi, int xs_lds, W4Plan plan, int ksplit, float* __restrict__ part,
+            float* __restrict__ part2) {
     // two LDS stages: the global loads of K-tile t+1 are in flight (registers) while tile t is multiplied, one barrier per tile
     __shared__ __attribute__((aligned(16))) bf16_t As[2][GBM * GLD];
     __shared__ __attribute__((aligned(16))) bf16_t Bs[2][GBN * GLD];
@@ -56,6 +61,10 @@ gemm_kernel(const bf16_t* __restrict__ A, int lda, int M, const void* __restrict
     const int lr = lane & 31, lh = lane >> 5;
     const int ktiles = K / GBK;
     const int Gs = W4 ? plan.Gs : ktiles;  // K-tiles per quantisation group
+    // split-K (short prompts: too few tiles to fill the chip): blockIdx.z owns K-tiles [kt_begin, kt_end), whole groups,
+    // and writes raw fp32 partial results; gemm_splitk_epilogue_kernel sums them in a fixed order and applies the epilogue
+    const int kt_per = SPLIT ? ktiles / ksplit : ktiles;
+    const int kt_begin = SPLIT ? (int)blockIdx.z * kt_per : 0, kt_end = kt_begin + kt_per;
     const int ngroups = W4 ? plan.ngroups : 1;
     constexpr int IM = GBM / 64, JN = GBN / 64;  // 32x32 MFMA tiles per wave: each wave owns (GBM/2) x (GBN/2)
     constexpr int AIT = GBM / 64;                // 16-byte A pieces per thread per K-tile
@@ -137,13 +146,13 @@ gemm_kernel(const bf16_t* __restrict__ A, int lda, int M, const void* __restrict
                 *reinterpret_cast<uint4*>(&Bs[st][(idx >> 2) * GLD + (idx & 3) * 8]) = v;
             }
         };
-        fetch(0);
+        fetch(kt_begin);
         __syncthreads();  // previous pass finished with the LDS stages; xs_l is filled
         stage(0);
         __syncthreads();
         uint32_t mtg[JN];  // int4: {scale, zero} of the current quantisation group for this lane's output columns
-        for (int kt = 0; kt < ktiles; ++kt) {
-            const int st = kt & 1;
+        for (int kt = kt_begin; kt < kt_end; ++kt) {
+            const int st = (kt - kt_begin) & 1;
             const int slab_now = slab;  // slab of tile kt (fetch() below may advance it)
             if (W4 && kt % Gs == 0) {
                 // requested at the START of the group and used at its end (Gs tiles later): the first version loaded it at
@@ -157,7 +166,7 @@ gemm_kernel(const bf16_t* __restrict__ A, int lda, int M, const void* __restrict
                     mtg[jn] = reinterpret_cast<const uint32_t*>(rec + plan.slab[gs].meta_off16)[g - plan.slab[gs].g0];
                 }
             }
-            if (kt + 1 < ktiles) fetch(kt + 1);
+            if (kt + 1 < kt_end) fetch(kt + 1);
             // ---- 2 k-steps of MFMA 32x32x16 on stage st
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
@@ -178,7 +187,7 @@ gemm_kernel(const bf16_t* __restrict__ A, int lda, int M, const void* __restrict
                     for (int jn = 0; jn < JN; ++jn)
                         acc[i][jn] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[jn], acc[i][jn], 0, 0, 0);
             }
-            if (W4 && ((kt + 1) % Gs == 0 || kt + 1 == ktiles)) {
+            if (W4 && ((kt + 1) % Gs == 0 || kt + 1 == kt_end)) {
                 // ---- quantisation-group boundary: fold the group's partial product into the result
                 const int g = kt / Gs;
 #pragma unroll
@@ -196,7 +205,7 @@ gemm_kernel(const bf16_t* __restrict__ A, int lda, int M, const void* __restrict
                         }
                 }
             }
-            if (kt + 1 < ktiles) stage(st ^ 1);  // stage st^1 was last read in iteration kt-1, before the barrier below it
+            if (kt + 1 < kt_end) stage(st ^ 1);  // stage st^1 was last read in iteration kt-1, before the barrier below it
             __syncthreads();
         }
         if (!W4) {
@@ -204,6 +213,21 @@ gemm_kernel(const bf16_t* __restrict__ A, int lda, int M, const void* __restrict
             for (int i = 0; i < IM; ++i)
 #pragma unroll
                 for (int jn = 0; jn < JN; ++jn) total[i][jn] = acc[i][jn];
+        }
+        if constexpr (SPLIT) {  // raw partial result of this K range (C layout of the 32x32 MFMA, see the epilogue below)
+            float* dst = (pass ? part2 : part) + (int64_t)blockIdx.z * M * N;
+#pragma unroll
+            for (int i = 0; i < IM; ++i)
+#pragma unroll
+                for (int jn = 0; jn < JN; ++jn) {
+                    const int col = n0 + wn * (GBN / 2) + jn * 32 + lr;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int row = m0 + wm * (GBM / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                        if (row < M && col < N) dst[(int64_t)row * N + col] = total[i][jn][r];
+                    }
+                }
+            continue;
         }
         if (npass == 2 && pass == 0) {
 #pragma unroll
@@ -217,6 +241,7 @@ gemm_kernel(const bf16_t* __restrict__ A, int lda, int M, const void* __restrict
                     }
         }
     }
+    if constexpr (SPLIT) return;
     // ---- epilogue: C layout of the 32x32 MFMA: column = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
 #pragma unroll
     for (int i = 0; i < IM; ++i)
@@ -241,8 +266,82 @@ gemm_kernel(const bf16_t* __restrict__ A, int lda, int M, const void* __restrict
         }
 }
 
+// split-K second stage: sum the partials in a fixed order and apply the epilogue (same rounding points as the one-pass kernel)
+__global__ void __launch_bounds__(256)
+gemm_splitk_epilogue_kernel(const float* __restrict__ part, const float* __restrict__ part2, int ksplit, int M, int N,
+                            const bf16_t* __restrict__ bias, const bf16_t* residual, int ldr, bf16_t* out, int ldo, int epi) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (int64_t)M * N) return;
+    const int row = (int)(t / N), col = (int)(t % N);
+    float a = 0.f, b = 0.f;
+    for (int z = 0; z < ksplit; ++z) {
+        a += part[((int64_t)z * M + row) * N + col];
+        if (epi == PARROT_EPI_SWIGLU) b += part2[((int64_t)z * M + row) * N + col];
+    }
+    bf16_t o;
+    if (epi == PARROT_EPI_SWIGLU)
+        o = f2bf(bf2f(f2bf(silu(rbf(a)))) * rbf(b));
+    else
+        o = apply_epilogue(epi, a, 0.f, bias, residual ? residual + (int64_t)row * ldr : nullptr, col);
+    out[(int64_t)row * ldo + col] = o;
+}
+
 // 128 x 128 tiles only when they alone give the chip >= 2 workgroups per CU; otherwise 64 x 64 (4x the workgroups)
 static bool gemm_big_tiles(int M, int N) { return (int64_t)((M + 127) / 128) * ((N + 127) / 128) >= 512; }
+
+// K splits for launches with too few tiles to fill the chip (short prompts): equal ranges of whole quantisation groups,
+// at least 8 K-tiles each, at most 8 splits, aiming at >= ~1536 workgroups
+static int gemm_ksplit(int M, int N, int K, int gs_tiles) {
+    static int env = -1;  // PARROT_GEMM_KSPLIT: 0 = never split (A/B), n = force
+    if (env < 0) {
+        const char* e = getenv("PARROT_GEMM_KSPLIT");
+        env = e ? atoi(e) : -2;
+    }
+    if (env == 0) return 1;
+    const int64_t tiles = gemm_big_tiles(M, N) ? (int64_t)((M + 127) / 128) * ((N + 127) / 128) : (int64_t)((M + 63) / 64) * ((N + 63) / 64);
+    const int ktiles = K / GBK;
+    int ks = env > 0 ? env : (int)(1536 / (tiles > 0 ? tiles : 1));
+    if (ks > 8) ks = 8;
+    while (ks > 1 && (ktiles % (ks * gs_tiles) != 0 || ktiles / ks < 8)) --ks;
+    return ks < 1 ? 1 : ks;
+}
+
+// launch the tiles (x ksplit) and, when K was split, the second stage
+template <bool W4>
+static int gemm_launch(int kid, const void* Wp, const void* W2p, const void* x, int ldx, int M, const void* bias, const void* residual,
+                       int ldr, void* out, int ldo, int N, int K, int epilogue, const float* xsum, float* part_ws, const W4Plan& plan,
+                       int gs_tiles, hipStream_t st) {
+    const int ksplit = gemm_ksplit(M, N, K, gs_tiles);
+    float* part = ksplit > 1 ? part_ws : nullptr;
+    float* part2 = (ksplit > 1 && epilogue == PARROT_EPI_SWIGLU) ? part_ws + (int64_t)ksplit * M * N : nullptr;
+    PARROT_REQUIRE(ksplit == 1 || part_ws != nullptr, "gemm: this shape splits K %d ways and needs the workspace of parrot_gemm_workspace_floats", ksplit);
+    int rc;
+#define PARROT_GEMM_GO(BMV, BNV, SPLITV)                                                                                       \
+    rc = launch(kid, gemm_kernel<W4, BMV, BNV, SPLITV>, grid, dim3(256), in_lds ? xb : 0, st, (const bf16_t*)x, ldx, M, Wp, W2p, N, K, \
+                xsum, (const bf16_t*)bias, (const bf16_t*)residual, ldr, (bf16_t*)out, ldo, epilogue, in_lds, plan, ksplit, part, part2)
+    if (gemm_big_tiles(M, N)) {
+        const size_t xb = W4 ? (size_t)128 * plan.ngroups * 4 : 0;
+        const int in_lds = W4 && xb <= 20 * 1024;
+        const dim3 grid((N + 127) / 128, (M + 127) / 128, ksplit);
+        if (ksplit > 1)
+            PARROT_GEMM_GO(128, 128, true);
+        else
+            PARROT_GEMM_GO(128, 128, false);
+    } else {
+        const size_t xb = W4 ? (size_t)64 * plan.ngroups * 4 : 0;
+        const int in_lds = W4 && xb <= 40 * 1024;
+        const dim3 grid((N + 63) / 64, (M + 63) / 64, ksplit);
+        if (ksplit > 1)
+            PARROT_GEMM_GO(64, 64, true);
+        else
+            PARROT_GEMM_GO(64, 64, false);
+    }
+#undef PARROT_GEMM_GO
+    if (rc != PARROT_OK || ksplit == 1) return rc;
+    const int64_t n = (int64_t)M * N;
+    return launch(kid, gemm_splitk_epilogue_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (const float*)part,
+                  (const float*)part2, ksplit, M, N, (const bf16_t*)bias, (const bf16_t*)residual, ldr, (bf16_t*)out, ldo, epilogue);
+}
 
 }  // namespace parrot
 
@@ -250,13 +349,25 @@ using namespace parrot;
 
 extern "C" {
 
-int64_t parrot_gemm_workspace_floats(int M, int K, int group) {
-    if (group <= 0 || group > K) group = K;
-    return (int64_t)M * ((K + group - 1) / group);
+// floats of workspace a GEMM call needs: the per-group activation sums (int4: group != 0) + the split-K partial results
+int64_t parrot_gemm_workspace_floats(int M, int N, int K, int group, int epilogue) {
+    int64_t n = 0;
+    int gs_tiles = 1;  // bf16: any K-tile boundary will do
+    if (group != 0) {
+        if (group < 0 || group > K) group = K;
+        n += (int64_t)M * ((K + group - 1) / group);
+        gs_tiles = group / GBK > 0 ? group / GBK : 1;
+    }
+    if (K % GBK == 0) {
+        const int ks = gemm_ksplit(M, N, K, gs_tiles);
+        if (ks > 1) n += (int64_t)ks * M * N * (epilogue == PARROT_EPI_SWIGLU ? 2 : 1);
+    }
+    return n;
 }
 
 int parrot_bf16_gemm(const void* W, const void* W2, const void* x, int ldx, int M, const void* bias, const void* residual,
-                     int ldr, void* out, int ldo, int N, int K, int epilogue, const parrot_norm_t* norm, void* stream) {
+                     int ldr, void* out, int ldo, int N, int K, int epilogue, const parrot_norm_t* norm, void* workspace,
+                     void* stream) {
     if (M <= 8) return parrot_bf16_gemv(W, W2, x, ldx, M, bias, residual, ldr, out, ldo, N, K, epilogue, norm, stream);
     int rc = check_linear_args("bf16_gemm", W, W2, x, ldx, M, residual, ldr, out, ldo, N, K, epilogue);
     if (rc != PARROT_OK) return rc;
@@ -265,14 +376,8 @@ int parrot_bf16_gemm(const void* W, const void* W2, const void* x, int ldx, int 
     PARROT_UNSUPPORTED(!(epilogue == PARROT_EPI_SWIGLU && bias), "bf16_gemm: SWIGLU epilogue takes no bias");
     PARROT_REQUIRE(M <= 65535 * 64, "bf16_gemm: M too large");
     W4Plan plan = {};
-    if (gemm_big_tiles(M, N)) {
-        const dim3 grid((N + 127) / 128, (M + 127) / 128);
-        return launch(K_BF16_GEMM, gemm_kernel<false, 128, 128>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, ldx, M, W, W2,
-                      N, K, (const float*)nullptr, (const bf16_t*)bias, (const bf16_t*)residual, ldr, (bf16_t*)out, ldo, epilogue, 0, plan);
-    }
-    const dim3 grid((N + 63) / 64, (M + 63) / 64);
-    return launch(K_BF16_GEMM, gemm_kernel<false, 64, 64>, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, ldx, M, W, W2, N, K,
-                  (const float*)nullptr, (const bf16_t*)bias, (const bf16_t*)residual, ldr, (bf16_t*)out, ldo, epilogue, 0, plan);
+    return gemm_launch<false>(K_BF16_GEMM, W, W2, x, ldx, M, bias, residual, ldr, out, ldo, N, K, epilogue, nullptr, (float*)workspace,
+                              plan, 1, (hipStream_t)stream);
 }
 
 int parrot_w4_gemm(const void* packed, const void* packed2, const void* x, int ldx, int M, const void* bias,
@@ -283,7 +388,7 @@ int parrot_w4_gemm(const void* packed, const void* packed2, const void* x, int l
     int rc = check_linear_args("w4_gemm", packed, packed2, x, ldx, M, residual, ldr, out, ldo, N, K, epilogue);
     if (rc != PARROT_OK) return rc;
     PARROT_UNSUPPORTED(norm == nullptr || norm->kind == 0, "w4_gemm: apply the norm to the rows first (parrot_rmsnorm / parrot_layernorm)");
-    PARROT_REQUIRE(workspace != nullptr, "w4_gemm: workspace of parrot_gemm_workspace_floats(M, K, group) floats required");
+    PARROT_REQUIRE(workspace != nullptr, "w4_gemm: workspace of parrot_gemm_workspace_floats(M, N, K, group, epilogue) floats required");
     PARROT_UNSUPPORTED(!(epilogue == PARROT_EPI_SWIGLU && bias), "w4_gemm: SWIGLU epilogue takes no bias");
     W4Plan plan;
     rc = w4_make_plan(N, K, group, &plan);
@@ -294,21 +399,9 @@ int parrot_w4_gemm(const void* packed, const void* packed2, const void* x, int l
     rc = launch(K_W4_GEMM, gemm_xsum_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (const bf16_t*)x, ldx, M, K, G,
                 plan.ngroups, (float*)workspace);
     if (rc != PARROT_OK) return rc;
-    // the tile's activation sums live in LDS when they fit next to the two stages (64 KB without opting in to more)
-    if (gemm_big_tiles(M, N)) {
-        const size_t xb = (size_t)128 * plan.ngroups * 4;
-        const int in_lds = xb <= 20 * 1024;
-        const dim3 grid((N + 127) / 128, (M + 127) / 128);
-        return launch(K_W4_GEMM, gemm_kernel<true, 128, 128>, grid, dim3(256), in_lds ? xb : 0, st, (const bf16_t*)x, ldx, M, packed,
-                      packed2, N, K, (const float*)workspace, (const bf16_t*)bias, (const bf16_t*)residual, ldr, (bf16_t*)out, ldo,
-                      epilogue, in_lds, plan);
-    }
-    const size_t xb = (size_t)64 * plan.ngroups * 4;
-    const int in_lds = xb <= 40 * 1024;
-    const dim3 grid((N + 63) / 64, (M + 63) / 64);
-    return launch(K_W4_GEMM, gemm_kernel<true, 64, 64>, grid, dim3(256), in_lds ? xb : 0, st, (const bf16_t*)x, ldx, M, packed, packed2,
-                  N, K, (const float*)workspace, (const bf16_t*)bias, (const bf16_t*)residual, ldr, (bf16_t*)out, ldo, epilogue,
-                  in_lds, plan);
+    // the split-K partials follow the activation sums in the workspace
+    return gemm_launch<true>(K_W4_GEMM, packed, packed2, x, ldx, M, bias, residual, ldr, out, ldo, N, K, epilogue, (const float*)workspace,
+                             (float*)workspace + n, plan, plan.Gs, st);
 }
 
 }  // extern "C"

@@ -94,10 +94,15 @@ def bf16_linear(weight: torch.Tensor, x: torch.Tensor, out: torch.Tensor, *, bia
         raise ParrotHipError("bf16_linear: weight must be contiguous bf16 (out_features, in_features)")
     M = x.shape[0]
     lib = _hip.load()
-    fn = lib.parrot_bf16_gemv if M <= GEMV_MAX_ROWS else lib.parrot_bf16_gemm
-    check(fn(ptr(weight), ptr(weight2), ptr(x), x.stride(0), M, ptr(_opt_vec(bias, N, "bias")),
-             ptr(residual), residual.stride(0) if residual is not None else 0, ptr(out), out.stride(0), N, K,
-             epilogue, _norm_arg(norm, K), stream()), "parrot_bf16_gemv/gemm")
+    args = (ptr(weight), ptr(weight2), ptr(x), x.stride(0), M, ptr(_opt_vec(bias, N, "bias")),
+            ptr(residual), residual.stride(0) if residual is not None else 0, ptr(out), out.stride(0), N, K,
+            epilogue, _norm_arg(norm, K))
+    if M <= GEMV_MAX_ROWS:
+        check(lib.parrot_bf16_gemv(*args, stream()), "parrot_bf16_gemv")
+    else:  # prefill: MFMA kernel; short prompts split K and need room for the partial results
+        n = lib.parrot_gemm_workspace_floats(M, N, K, 0, epilogue)
+        ws = torch.empty((n,), dtype=torch.float32, device=x.device) if n > 0 else None
+        check(lib.parrot_bf16_gemm(*args, ptr(ws), stream()), "parrot_bf16_gemm")
     return out
 
 
@@ -136,7 +141,8 @@ def w4_linear(packed: torch.Tensor, N: int, K: int, group: int, x: torch.Tensor,
     if M <= GEMV_MAX_ROWS:
         check(lib.parrot_w4_gemv(*args, stream()), "parrot_w4_gemv")
     else:  # prefill: MFMA kernel; needs the per-group activation sums workspace
-        ws = torch.empty((max(1, lib.parrot_gemm_workspace_floats(M, K, group)),), dtype=torch.float32, device=x.device)
+        ws = torch.empty((max(1, lib.parrot_gemm_workspace_floats(M, N, K, group if group > 0 else -1, epilogue)),),
+                         dtype=torch.float32, device=x.device)
         check(lib.parrot_w4_gemm(*args, ptr(ws), stream()), "parrot_w4_gemm")
     return out
 
