@@ -203,6 +203,10 @@ def main() -> None:
 
     with torch.no_grad():
         sess = _session(model, total, total, greedy=True)
+        # one untimed prefill first: the int4 weights are repacked to the kernel layout lazily at first use (a one-time
+        # load cost, 161 repack launches), workspaces are allocated, code objects are loaded
+        sess.prefill(prompt.to(device))
+        torch.cuda.synchronize(device)
         t_pre = time.perf_counter()
         logits = sess.prefill(prompt.to(device))
         L.ops.argmax_advance(logits, sess.tokens, sess.pos)
