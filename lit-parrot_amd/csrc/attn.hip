@@ -72,6 +72,37 @@ rope_kvappend_kernel(const bf16_t* __restrict__ qkv, int ldqkv, int M, const __h
 // ------------------------------------------------------------------------------------------ decode attention
 constexpr int kAttnWaves = 4;
 
+// sum over the LPR lanes that share a key row (LPR = 4, 8 or 16 consecutive lanes); every lane of the group gets the
+// total.  DPP only: no LDS crossbar (ds_bpermute) and no lgkmcnt waits in the key loop's dependent chain.
+template <int LPR>
+__device__ __forceinline__ float group_sum(float v) {
+    v += dpp0<0xB1>(v);                    // quad_perm [1,0,3,2]
+    v += dpp0<0x4E>(v);                    // quad_perm [2,3,0,1]
+    if (LPR >= 8) v += dpp0<0x141>(v);     // row_half_mirror: the two quads of an 8-lane group
+    if (LPR >= 16) v += dpp0<0x128>(v);    // row_ror:8: the two halves of a 16-lane row
+    return v;
+}
+
+// all-reduce over the 64 / LPR row slots of a wave (lanes with the same lane % LPR): DPP rotations inside the 16-lane rows,
+// then the gfx950 lane swaps across rows (v_permlane16_swap / v_permlane32_swap with both operands the same register
+// return the two halves, which are then combined) - no ds_bpermute.
+template <int LPR, bool MAX>
+__device__ __forceinline__ float slot_allreduce(float v) {
+    auto op = [](float a, float b) { return MAX ? fmaxf(a, b) : a + b; };
+    if (LPR <= 4) v = op(v, dpp0<0x124>(v));  // row_ror:4
+    if (LPR <= 8) v = op(v, dpp0<0x128>(v));  // row_ror:8 - every lane now holds its 16-lane row's result
+    {
+        const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+        v = op(__uint_as_float(r[0]), __uint_as_float(r[1]));  // rows 0+1 and 2+3
+    }
+    {
+        const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+        v = op(__uint_as_float(r[0]), __uint_as_float(r[1]));  // both halves
+    }
+    return v;
+}
+
+
 // partial state layout in the workspace: [M][n_head][nsplit][hs + 2] floats: acc[hs], m, l
 // HQ = query heads of the group processed in one pass over the K/V rows (1 for MHA, up to 4 for GQA/MQA)
 template <int HS, int HQ>
@@ -81,9 +112,9 @@ attn_decode_kernel(const bf16_t* __restrict__ q, const int32_t* __restrict__ pos
                    float* __restrict__ ws, bf16_t* __restrict__ y, int ldy) {
     constexpr int LPR = HS / 8;    // lanes per K/V row
     constexpr int RPW = 64 / LPR;  // rows per wave instruction
-    constexpr int NSLOT = kAttnWaves * RPW;
-    __shared__ float sh_acc[HQ][NSLOT][HS];
-    __shared__ float sh_m[HQ][NSLOT], sh_l[HQ][NSLOT];
+    constexpr int STRIDE = kAttnWaves * RPW;
+    __shared__ float sh_acc[HQ][kAttnWaves][HS];  // one merged state per wave
+    __shared__ float sh_m[HQ][kAttnWaves], sh_l[HQ][kAttnWaves];
 
     const int g = blockIdx.x, split = blockIdx.y, m = blockIdx.z;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -93,72 +124,81 @@ attn_decode_kernel(const bf16_t* __restrict__ q, const int32_t* __restrict__ pos
     const int n_valid = min(pos + 1, S);  // slots 0..n_valid-1 hold the admitted keys
     const int per = (S + nsplit - 1) / nsplit;
     const int s_begin = split * per, s_end = min(n_valid, s_begin + per);
+    const int s_last = max(s_end - 1, 0);
     const float scale = 1.0f / sqrtf((float)HS);
     const uint4* kc = reinterpret_cast<const uint4*>(k_cache + (int64_t)g * S * HS);
     const uint4* vc = reinterpret_cast<const uint4*>(v_cache + (int64_t)g * S * HS);
-    const int slot = wave * RPW + sub;
+    const int s_first = s_begin + wave * RPW;
 
     for (int h0 = 0; h0 < q_per_kv; h0 += HQ) {
-        float qf[HQ][8];
+        // the same key loop as the fused single-token kernel below: packed-bf16 dot2 scores, DPP sums over the lanes of a
+        // key, two K/V register sets in ping-pong with unconditional (clamped) loads, slots merged in-wave
+        uint32_t qp[HQ][4];
         float mrun[HQ], lrun[HQ], acc[HQ][8];
 #pragma unroll
         for (int hh = 0; hh < HQ; ++hh) {
             const int head = g * q_per_kv + min(h0 + hh, q_per_kv - 1);
             const uint4 qv = reinterpret_cast<const uint4*>(q + ((int64_t)m * n_head + head) * HS)[dl];
-            const uint32_t dw[4] = {qv.x, qv.y, qv.z, qv.w};
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                qf[hh][2 * j] = bflo(dw[j]) * scale;
-                qf[hh][2 * j + 1] = bfhi(dw[j]) * scale;
-            }
+            qp[hh][0] = qv.x;
+            qp[hh][1] = qv.y;
+            qp[hh][2] = qv.z;
+            qp[hh][3] = qv.w;
             mrun[hh] = -INFINITY;
             lrun[hh] = 0.f;
 #pragma unroll
             for (int e = 0; e < 8; ++e) acc[hh][e] = 0.f;
         }
-        for (int s0 = s_begin + wave * RPW; s0 < s_end; s0 += kAttnWaves * RPW) {
-            const int s = s0 + sub;
+        auto step = [&](const uint4 kv, const uint4 vv, int s) {
             const bool ok = s < s_end;
-            const int sc = ok ? s : s_end - 1;
-            const uint4 kv = kc[(int64_t)sc * LPR + dl];
-            const uint4 vv = vc[(int64_t)sc * LPR + dl];
-            const uint32_t kd[4] = {kv.x, kv.y, kv.z, kv.w};
             const uint32_t vd[4] = {vv.x, vv.y, vv.z, vv.w};
-            float kf[8], vf[8];
+            float vf[8];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                kf[2 * j] = bflo(kd[j]);
-                kf[2 * j + 1] = bfhi(kd[j]);
-                vf[2 * j] = bflo(vd[j]);
-                vf[2 * j + 1] = bfhi(vd[j]);
+            for (int jq = 0; jq < 4; ++jq) {
+                vf[2 * jq] = bflo(vd[jq]);
+                vf[2 * jq + 1] = bfhi(vd[jq]);
             }
 #pragma unroll
             for (int hh = 0; hh < HQ; ++hh) {
-                float sc_ = 0.f;
+                float p0 = dot2_bf16(kv.x, qp[hh][0], 0.f), p1 = dot2_bf16(kv.y, qp[hh][1], 0.f);
+                p0 = dot2_bf16(kv.z, qp[hh][2], p0);
+                p1 = dot2_bf16(kv.w, qp[hh][3], p1);
+                const float sc_ = ok ? group_sum<LPR>(p0 + p1) * scale : -INFINITY;
+                const float mn = fmaxf(mrun[hh], sc_);
+                const float corr = (mn == -INFINITY) ? 1.f : __expf(mrun[hh] - mn);
+                const float p = (mn == -INFINITY) ? 0.f : __expf(sc_ - mn);
+                lrun[hh] = lrun[hh] * corr + p;
 #pragma unroll
-                for (int e = 0; e < 8; ++e) sc_ = fmaf(qf[hh][e], kf[e], sc_);
-#pragma unroll
-                for (int off = LPR / 2; off >= 1; off >>= 1) sc_ += __shfl_xor(sc_, off, 64);
-                if (ok) {
-                    const float mn = fmaxf(mrun[hh], sc_);
-                    const float corr = __expf(mrun[hh] - mn);  // exp(-inf) = 0 on the first key
-                    const float p = __expf(sc_ - mn);
-                    lrun[hh] = lrun[hh] * corr + p;
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) acc[hh][e] = acc[hh][e] * corr + p * vf[e];
-                    mrun[hh] = mn;
-                }
+                for (int e = 0; e < 8; ++e) acc[hh][e] = acc[hh][e] * corr + p * vf[e];
+                mrun[hh] = mn;
             }
+        };
+        const int sc0 = min(s_first + sub, s_last);
+        uint4 k0 = kc[(int64_t)sc0 * LPR + dl], v0 = vc[(int64_t)sc0 * LPR + dl];
+        for (int s0 = s_first; s0 < s_end; s0 += 2 * STRIDE) {
+            const int sn1 = min(s0 + STRIDE + sub, s_last);
+            const uint4 k1 = kc[(int64_t)sn1 * LPR + dl], v1 = vc[(int64_t)sn1 * LPR + dl];
+            step(k0, v0, s0 + sub);
+            const int sn2 = min(s0 + 2 * STRIDE + sub, s_last);
+            k0 = kc[(int64_t)sn2 * LPR + dl];
+            v0 = vc[(int64_t)sn2 * LPR + dl];
+            if (s0 + STRIDE < s_end) step(k1, v1, s0 + STRIDE + sub);  // wave-uniform
         }
-        // publish every (wave, row-slot) state, then merge: thread d of head hh sums over the slots
-        __syncthreads();
+        __syncthreads();  // the previous head chunk's merge has finished reading the LDS states
 #pragma unroll
         for (int hh = 0; hh < HQ; ++hh) {
+            const float mw = slot_allreduce<LPR, true>(mrun[hh]);
+            const float c = (mrun[hh] == -INFINITY) ? 0.f : __expf(mrun[hh] - mw);
+            lrun[hh] = slot_allreduce<LPR, false>(lrun[hh] * c);
 #pragma unroll
-            for (int e = 0; e < 8; ++e) sh_acc[hh][slot][dl * 8 + e] = acc[hh][e];
-            if (dl == 0) {
-                sh_m[hh][slot] = mrun[hh];
-                sh_l[hh][slot] = lrun[hh];
+            for (int e = 0; e < 8; ++e) acc[hh][e] = slot_allreduce<LPR, false>(acc[hh][e] * c);
+            mrun[hh] = mw;
+            if (sub == 0) {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) sh_acc[hh][wave][dl * 8 + e] = acc[hh][e];
+                if (dl == 0) {
+                    sh_m[hh][wave] = mrun[hh];
+                    sh_l[hh][wave] = lrun[hh];
+                }
             }
         }
         __syncthreads();
@@ -166,9 +206,9 @@ attn_decode_kernel(const bf16_t* __restrict__ q, const int32_t* __restrict__ pos
             const int hh = idx / HS, d = idx % HS;
             if (h0 + hh < q_per_kv) {
                 float mx = -INFINITY;
-                for (int t = 0; t < NSLOT; ++t) mx = fmaxf(mx, sh_m[hh][t]);
+                for (int t = 0; t < kAttnWaves; ++t) mx = fmaxf(mx, sh_m[hh][t]);
                 float l = 0.f, a = 0.f;
-                for (int t = 0; t < NSLOT; ++t) {
+                for (int t = 0; t < kAttnWaves; ++t) {
                     const float mt = sh_m[hh][t];
                     const float w = (mt == -INFINITY) ? 0.f : __expf(mt - mx);
                     l += sh_l[hh][t] * w;
@@ -224,36 +264,6 @@ __device__ __forceinline__ void store_agent(float* p, float v) {
 }
 __device__ __forceinline__ float load_agent(const float* p) {
     return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-
-// sum over the LPR lanes that share a key row (LPR = 4, 8 or 16 consecutive lanes); every lane of the group gets the
-// total.  DPP only: no LDS crossbar (ds_bpermute) and no lgkmcnt waits in the key loop's dependent chain.
-template <int LPR>
-__device__ __forceinline__ float group_sum(float v) {
-    v += dpp0<0xB1>(v);                    // quad_perm [1,0,3,2]
-    v += dpp0<0x4E>(v);                    // quad_perm [2,3,0,1]
-    if (LPR >= 8) v += dpp0<0x141>(v);     // row_half_mirror: the two quads of an 8-lane group
-    if (LPR >= 16) v += dpp0<0x128>(v);    // row_ror:8: the two halves of a 16-lane row
-    return v;
-}
-
-// all-reduce over the 64 / LPR row slots of a wave (lanes with the same lane % LPR): DPP rotations inside the 16-lane rows,
-// then the gfx950 lane swaps across rows (v_permlane16_swap / v_permlane32_swap with both operands the same register
-// return the two halves, which are then combined) - no ds_bpermute.
-template <int LPR, bool MAX>
-__device__ __forceinline__ float slot_allreduce(float v) {
-    auto op = [](float a, float b) { return MAX ? fmaxf(a, b) : a + b; };
-    if (LPR <= 4) v = op(v, dpp0<0x124>(v));  // row_ror:4
-    if (LPR <= 8) v = op(v, dpp0<0x128>(v));  // row_ror:8 - every lane now holds its 16-lane row's result
-    {
-        const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
-        v = op(__uint_as_float(r[0]), __uint_as_float(r[1]));  // rows 0+1 and 2+3
-    }
-    {
-        const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
-        v = op(__uint_as_float(r[0]), __uint_as_float(r[1]));  // both halves
-    }
-    return v;
 }
 
 // diagnostic stamps (tools/microbench.py --attn): 100 MHz clock of workgroup (0,0,0) at phase boundaries; the buffer

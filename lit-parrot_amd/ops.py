@@ -217,16 +217,13 @@ def rope_kvappend(qkv: torch.Tensor, cos: torch.Tensor, sin: torch.Tensor, n_ele
 
 
 def attn_nsplit(n_groups: int, S: int, q_per_kv: int = 1, M: int = 1) -> int:
-    """Sequence splits of the decode-attention kernels.
-
-    Single new token (fused kernel, 16 waves per workgroup): one workgroup walks up to ~1k keys by itself, so windows up
-    to 1024 take no split at all (no partials / ticket / second pass) and longer ones ceil(S / 1024) splits.
-    Several rows (prefill kernel, 4 waves): about 32 keys per workgroup, bounded by ~1024 workgroups per row and 64 splits."""
+    """Sequence splits of the decode-attention kernels: one workgroup walks up to ~1k keys by itself, so windows up to
+    1024 take no split at all (no partials / ticket / second pass) and longer ones ceil(S / 1024) splits.  The same rule
+    serves the multi-row (prefill) kernel: with one workgroup per (row, head, 32 keys) a 512-token prompt launched 393 K
+    mostly empty workgroups per layer and was bound by workgroup dispatch (315 us per layer; 60 us without the split)."""
     chunks = (q_per_kv + 3) // 4 if q_per_kv > 2 else 1
     cap = max(1, 1024 // (n_groups * chunks))
-    if M == 1:
-        return max(1, min(-(-S // 1024), cap, 64))
-    return max(1, min(S // 32, cap, 64))
+    return max(1, min(-(-S // 1024), cap, 64))
 
 
 def attn_workspace(M: int, n_head: int, hs: int, nsplit: int, device) -> torch.Tensor:
