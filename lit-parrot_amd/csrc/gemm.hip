@@ -45,7 +45,7 @@ gemm_xsum_kernel(const bf16_t* __restrict__ x, int ldx, int M, int K, int G, int
 
 // SPLIT = the split-K instantiation (raw fp32 partials out, no epilogue); kept apart from the one-pass kernel so that the
 // latter's register allocation is not disturbed (as a run-time switch it cost the bf16 kernel 56 more VGPRs and 30 %).
-template <bool W4, int GBM, int GBN, bool SPLIT>
+template <bool W4, int GBM, int GBN, bool SPLIT, bool SWI>
 __global__ void __launch_bounds__(256)
 gemm_kernel(const bf16_t* __restrict__ A, int lda, int M, const void* __restrict__ Wv, const void* __restrict__ W2v, int N,
             int K, const float* __restrict__ xsum, const bf16_t* __restrict__ bias, const bf16_t* residual, int ldr,
@@ -78,13 +78,15 @@ gemm_kernel(const bf16_t* __restrict__ A, int lda, int M, const void* __restrict
         }
     }
 
-    f32x16_t total[IM][JN];
-    uint32_t gate[IM][JN][8];  // SwiGLU: bf16(silu(bf16(fc_1))) of the first pass, packed
-    const int npass = (epi == PARROT_EPI_SWIGLU) ? 2 : 1;
+    // `total` (int4: the result across quantisation groups) and `gate` (SwiGLU) only exist in the instantiations that
+    // need them: the bf16 kernel reads its accumulators directly in the epilogue
+    f32x16_t total[W4 ? IM : 1][W4 ? JN : 1];
+    uint32_t gate[SWI ? IM : 1][SWI ? JN : 1][8];  // SwiGLU: bf16(silu(bf16(fc_1))) of the first pass, packed
+    const int npass = SWI ? 2 : 1;
 
+    f32x16_t acc[IM][JN];
     for (int pass = 0; pass < npass; ++pass) {
         const void* Wp = pass ? W2v : Wv;
-        f32x16_t acc[IM][JN];
 #pragma unroll
         for (int i = 0; i < IM; ++i)
 #pragma unroll
@@ -92,7 +94,7 @@ gemm_kernel(const bf16_t* __restrict__ A, int lda, int M, const void* __restrict
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     acc[i][jn][r] = 0.f;
-                    total[i][jn][r] = 0.f;
+                    if (W4) total[W4 ? i : 0][W4 ? jn : 0][r] = 0.f;
                 }
         uint4 ra[AIT];
         uint4 rb[BIT];    // bf16 weights
@@ -200,7 +202,7 @@ gemm_kernel(const bf16_t* __restrict__ A, int lda, int M, const void* __restrict
                         for (int r = 0; r < 16; ++r) {
                             const int lm = wm * (GBM / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
                             const float xs = xs_lds ? xs_l[lm * ngroups + g] : xsum[(int64_t)min(m0 + lm, M - 1) * ngroups + g];
-                            total[i][jn][r] += sc * (acc[i][jn][r] - zz * xs);
+                            total[W4 ? i : 0][W4 ? jn : 0][r] += sc * (acc[i][jn][r] - zz * xs);
                             acc[i][jn][r] = 0.f;
                         }
                 }
@@ -208,12 +210,7 @@ gemm_kernel(const bf16_t* __restrict__ A, int lda, int M, const void* __restrict
             if (kt + 1 < kt_end) stage(st ^ 1);  // stage st^1 was last read in iteration kt-1, before the barrier below it
             __syncthreads();
         }
-        if (!W4) {
-#pragma unroll
-            for (int i = 0; i < IM; ++i)
-#pragma unroll
-                for (int jn = 0; jn < JN; ++jn) total[i][jn] = acc[i][jn];
-        }
+#define GEMM_RESULT(I, JNN, R) (W4 ? total[W4 ? (I) : 0][W4 ? (JNN) : 0][R] : acc[I][JNN][R])
         if constexpr (SPLIT) {  // raw partial result of this K range (C layout of the 32x32 MFMA, see the epilogue below)
             float* dst = (pass ? part2 : part) + (int64_t)blockIdx.z * M * N;
 #pragma unroll
@@ -224,20 +221,20 @@ gemm_kernel(const bf16_t* __restrict__ A, int lda, int M, const void* __restrict
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         const int row = m0 + wm * (GBM / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                        if (row < M && col < N) dst[(int64_t)row * N + col] = total[i][jn][r];
+                        if (row < M && col < N) dst[(int64_t)row * N + col] = GEMM_RESULT(i, jn, r);
                     }
                 }
             continue;
         }
-        if (npass == 2 && pass == 0) {
+        if (SWI && pass == 0) {
 #pragma unroll
             for (int i = 0; i < IM; ++i)
 #pragma unroll
                 for (int jn = 0; jn < JN; ++jn)
 #pragma unroll
                     for (int r = 0; r < 16; r += 2) {
-                        const bf16_t g0 = f2bf(silu(rbf(total[i][jn][r]))), g1 = f2bf(silu(rbf(total[i][jn][r + 1])));
-                        gate[i][jn][r >> 1] = (uint32_t)g0 | ((uint32_t)g1 << 16);
+                        const bf16_t g0 = f2bf(silu(rbf(GEMM_RESULT(i, jn, r)))), g1 = f2bf(silu(rbf(GEMM_RESULT(i, jn, r + 1))));
+                        gate[SWI ? i : 0][SWI ? jn : 0][r >> 1] = (uint32_t)g0 | ((uint32_t)g1 << 16);
                     }
         }
     }
@@ -253,18 +250,20 @@ gemm_kernel(const bf16_t* __restrict__ A, int lda, int M, const void* __restrict
                 const int row = m0 + wm * (GBM / 2) + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
                 if (row < M && col < N) {
                     bf16_t o;
-                    if (epi == PARROT_EPI_SWIGLU) {
-                        const uint32_t gp = gate[i][jn][r >> 1];
+                    if (SWI) {
+                        const uint32_t gp = gate[SWI ? i : 0][SWI ? jn : 0][r >> 1];
                         const float gv = (r & 1) ? bfhi(gp) : bflo(gp);
-                        o = f2bf(gv * rbf(total[i][jn][r]));
+                        o = f2bf(gv * rbf(GEMM_RESULT(i, jn, r)));
                     } else {
-                        o = apply_epilogue(epi, total[i][jn][r], 0.f, bias, residual ? residual + (int64_t)row * ldr : nullptr, col);
+                        o = apply_epilogue(epi, GEMM_RESULT(i, jn, r), 0.f, bias, residual ? residual + (int64_t)row * ldr : nullptr, col);
                     }
                     out[(int64_t)row * ldo + col] = o;
                 }
             }
         }
 }
+
+#undef GEMM_RESULT
 
 // split-K second stage: sum the partials in a fixed order and apply the epilogue (same rounding points as the one-pass kernel)
 __global__ void __launch_bounds__(256)
@@ -287,7 +286,14 @@ gemm_splitk_epilogue_kernel(const float* __restrict__ part, const float* __restr
 }
 
 // 128 x 128 tiles only when they alone give the chip >= 2 workgroups per CU; otherwise 64 x 64 (4x the workgroups)
-static bool gemm_big_tiles(int M, int N) { return (int64_t)((M + 127) / 128) * ((N + 127) / 128) >= 512; }
+static bool gemm_big_tiles(int M, int N) {
+    static int env = -1;  // PARROT_GEMM_BIG_MIN: minimum number of 128 x 128 tiles for the big-tile kernel (experiment hook)
+    if (env < 0) {
+        const char* e = getenv("PARROT_GEMM_BIG_MIN");
+        env = e ? atoi(e) : 512;
+    }
+    return (int64_t)((M + 127) / 128) * ((N + 127) / 128) >= env;
+}
 
 // K splits for launches with too few tiles to fill the chip (short prompts): equal ranges of whole quantisation groups,
 // at least 8 K-tiles each, at most 8 splits, aiming at >= ~1536 workgroups
@@ -316,9 +322,14 @@ static int gemm_launch(int kid, const void* Wp, const void* W2p, const void* x, 
     float* part2 = (ksplit > 1 && epilogue == PARROT_EPI_SWIGLU) ? part_ws + (int64_t)ksplit * M * N : nullptr;
     PARROT_REQUIRE(ksplit == 1 || part_ws != nullptr, "gemm: this shape splits K %d ways and needs the workspace of parrot_gemm_workspace_floats", ksplit);
     int rc;
-#define PARROT_GEMM_GO(BMV, BNV, SPLITV)                                                                                       \
-    rc = launch(kid, gemm_kernel<W4, BMV, BNV, SPLITV>, grid, dim3(256), in_lds ? xb : 0, st, (const bf16_t*)x, ldx, M, Wp, W2p, N, K, \
-                xsum, (const bf16_t*)bias, (const bf16_t*)residual, ldr, (bf16_t*)out, ldo, epilogue, in_lds, plan, ksplit, part, part2)
+#define PARROT_GEMM_GO2(BMV, BNV, SPLITV, SWIV)                                                                                \
+    rc = launch(kid, gemm_kernel<W4, BMV, BNV, SPLITV, SWIV>, grid, dim3(256), in_lds ? xb : 0, st, (const bf16_t*)x, ldx, M, Wp, W2p, N, \
+                K, xsum, (const bf16_t*)bias, (const bf16_t*)residual, ldr, (bf16_t*)out, ldo, epilogue, in_lds, plan, ksplit, part, part2)
+#define PARROT_GEMM_GO(BMV, BNV, SPLITV)                       \
+    if (epilogue == PARROT_EPI_SWIGLU)                         \
+        PARROT_GEMM_GO2(BMV, BNV, SPLITV, true);               \
+    else                                                       \
+        PARROT_GEMM_GO2(BMV, BNV, SPLITV, false)
     if (gemm_big_tiles(M, N)) {
         const size_t xb = W4 ? (size_t)128 * plan.ngroups * 4 : 0;
         const int in_lds = W4 && xb <= 20 * 1024;
@@ -337,6 +348,7 @@ static int gemm_launch(int kid, const void* Wp, const void* W2p, const void* x, 
             PARROT_GEMM_GO(64, 64, false);
     }
 #undef PARROT_GEMM_GO
+#undef PARROT_GEMM_GO2
     if (rc != PARROT_OK || ksplit == 1) return rc;
     const int64_t n = (int64_t)M * N;
     return launch(kid, gemm_splitk_epilogue_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (const float*)part,
