@@ -577,6 +577,95 @@ static int w8_fused_launch(const void* CB, const void* CB2, const void* SCB, con
                   (const bf16_t*)residual, (bf16_t*)out, N, K, wps, nslabs, epi, iters, na);
 }
 
+// ------------------------------------------------------------------------------------------ int8 GEMM (prefill)
+// Many token rows: C32[M, N] = CA[M, K] . CB[N, K]^T on the matrix cores (v_mfma_i32_32x32x32_i8: lane l holds 16 int8 of
+// row l & 31 at k = 16 (l >> 5) ..), then the mm_dequant / outlier / epilogue arithmetic of the GEMV per element.
+// Same tiling as gemm.hip (64 x 64 tile, 4 waves as 2 x 2, one 32 x 32 MFMA tile per wave, K-tile 64 bytes = two MFMA
+// k-steps, two LDS stages with 80-byte rows, register prefetch of the next K-tile).  The first version ran the GEMV once
+// per row (128 prompt tokens: 103 ms).
+typedef int i32x16_t __attribute__((ext_vector_type(16)));
+typedef int i32x4_t __attribute__((ext_vector_type(4)));
+constexpr int W8BK = 64;   // K-tile in bytes (= int8 elements)
+constexpr int W8LD = 80;   // LDS row stride in bytes
+
+template <bool SWI>
+__global__ void __launch_bounds__(256)
+w8_gemm_kernel(const int8_t* __restrict__ A, const int8_t* __restrict__ CB, const int8_t* __restrict__ CB2,
+               const float* __restrict__ SCB, const float* __restrict__ SCB2, const float* __restrict__ xout,
+               const float* __restrict__ sca, const int32_t* __restrict__ nout, const int32_t* __restrict__ oidx,
+               const bf16_t* __restrict__ bias, const bf16_t* residual, int ldr, bf16_t* out, int ldo, int M, int N, int K, int epi) {
+    __shared__ __attribute__((aligned(16))) unsigned char As[2][64 * W8LD];
+    __shared__ __attribute__((aligned(16))) unsigned char Bs[2][64 * W8LD];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
+    const int lr = lane & 31, lh = lane >> 5;
+    const int ktiles = K / W8BK;
+    // thread t moves the 16-byte piece (row t >> 2, piece t & 3) of both tiles
+    const int prow = tid >> 2, ppc = tid & 3;
+    const int64_t am = min(m0 + prow, M - 1), bn = min(n0 + prow, N - 1);
+    float res[2][16];
+    const int npass = SWI ? 2 : 1;
+    for (int pass = 0; pass < npass; ++pass) {
+        const int8_t* Wp = pass ? CB2 : CB;
+        i32x16_t acc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[r] = 0;
+        uint4 ra = *reinterpret_cast<const uint4*>(A + am * K + ppc * 16);
+        uint4 rb = *reinterpret_cast<const uint4*>(Wp + bn * K + ppc * 16);
+        __syncthreads();
+        *reinterpret_cast<uint4*>(&As[0][prow * W8LD + ppc * 16]) = ra;
+        *reinterpret_cast<uint4*>(&Bs[0][prow * W8LD + ppc * 16]) = rb;
+        __syncthreads();
+        for (int kt = 0; kt < ktiles; ++kt) {
+            const int st = kt & 1;
+            const int kn = min(kt + 1, ktiles - 1);  // clamped: unconditional loads
+            ra = *reinterpret_cast<const uint4*>(A + am * K + (int64_t)kn * W8BK + ppc * 16);
+            rb = *reinterpret_cast<const uint4*>(Wp + bn * K + (int64_t)kn * W8BK + ppc * 16);
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                const uint4 va = *reinterpret_cast<const uint4*>(&As[st][(wm * 32 + lr) * W8LD + s2 * 32 + lh * 16]);
+                const uint4 vb = *reinterpret_cast<const uint4*>(&Bs[st][(wn * 32 + lr) * W8LD + s2 * 32 + lh * 16]);
+                acc = __builtin_amdgcn_mfma_i32_32x32x32_i8(__builtin_bit_cast(i32x4_t, va), __builtin_bit_cast(i32x4_t, vb), acc, 0, 0, 0);
+            }
+            *reinterpret_cast<uint4*>(&As[st ^ 1][prow * W8LD + ppc * 16]) = ra;  // stage st^1 was last read in step kt-1
+            *reinterpret_cast<uint4*>(&Bs[st ^ 1][prow * W8LD + ppc * 16]) = rb;
+            __syncthreads();
+        }
+        // ---- dequantise this pass: C layout of the 32x32 MFMA: column = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
+        const int col = n0 + wn * 32 + lr;
+        const int colc = min(col, N - 1);
+        const float scb = (pass ? SCB2 : SCB)[colc];
+        const float b = (bias != nullptr && pass == 0) ? bf2f(bias[colc]) : 0.f;
+        const int8_t* wrow = Wp + (int64_t)colc * K;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int row = min(m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh, M - 1);
+            const float sa = sca[row];
+            // separately rounded fp32 products and sum (no FMA), the order mm_dequant uses (as in the GEMV)
+            float v = rhalf(__fadd_rn(__fmul_rn(__fmul_rn(__fmul_rn((float)acc[r], kMmDequant), sa), scb), b));
+            const int no = nout[row];
+            if (no > 0) {  // mixed-precision decomposition over the row's outlier columns
+                float o = 0.f;
+                for (int t = 0; t < no; ++t) {
+                    const int k = oidx[(int64_t)row * K + t];
+                    o += xout[(int64_t)row * K + k] * rhalf(__fdiv_rn(__fmul_rn((float)wrow[k], scb), 127.0f));
+                }
+                v = rhalf(v + rhalf(o));
+            }
+            res[pass][r] = v;
+        }
+    }
+    const int col = n0 + wn * 32 + lr;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int row = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        if (row < M && col < N)
+            out[(int64_t)row * ldo + col] =
+                apply_epilogue(epi, res[0][r], SWI ? res[1][r] : 0.f, nullptr, residual ? residual + (int64_t)row * ldr : nullptr, col);
+    }
+}
+
 }  // namespace parrot
 
 using namespace parrot;
@@ -622,11 +711,21 @@ int parrot_w8_gemv(const void* CB, const void* SCB, const void* xq, const void* 
         CB2 = (const int8_t*)CB + (int64_t)N * K;
         SCB2 = (const float*)SCB + N;
     }
+    hipStream_t st = (hipStream_t)stream;
+    if (M > 8 && K % W8BK == 0) {  // many rows (prefill): matrix cores
+        const dim3 grid((N + 63) / 64, (M + 63) / 64);
+        if (epilogue == PARROT_EPI_SWIGLU)
+            return launch(K_W8_GEMV, w8_gemm_kernel<true>, grid, dim3(256), 0, st, (const int8_t*)xq, (const int8_t*)CB, (const int8_t*)CB2,
+                          (const float*)SCB, (const float*)SCB2, (const float*)xout, (const float*)sca, (const int32_t*)nout,
+                          (const int32_t*)oidx, (const bf16_t*)bias, (const bf16_t*)residual, ldr, (bf16_t*)out, ldo, M, N, K, epilogue);
+        return launch(K_W8_GEMV, w8_gemm_kernel<false>, grid, dim3(256), 0, st, (const int8_t*)xq, (const int8_t*)CB, (const int8_t*)CB2,
+                      (const float*)SCB, (const float*)SCB2, (const float*)xout, (const float*)sca, (const int32_t*)nout,
+                      (const int32_t*)oidx, (const bf16_t*)bias, (const bf16_t*)residual, ldr, (bf16_t*)out, ldo, M, N, K, epilogue);
+    }
     const int chunks = K / 16;
     const int nslabs = (chunks + 255) / 256;
     const int per_slab = (chunks + nslabs - 1) / nslabs;
     const int jn = (per_slab + 63) / 64;
-    hipStream_t st = (hipStream_t)stream;
     if (jn <= 1) return w8_launch<1>(CB, CB2, SCB, SCB2, xq, xout, sca, nout, oidx, M, bias, residual, ldr, out, ldo, N, K, epilogue, nslabs, st);
     if (jn <= 2) return w8_launch<2>(CB, CB2, SCB, SCB2, xq, xout, sca, nout, oidx, M, bias, residual, ldr, out, ldo, N, K, epilogue, nslabs, st);
     return w8_launch<4>(CB, CB2, SCB, SCB2, xq, xout, sca, nout, oidx, M, bias, residual, ldr, out, ldo, N, K, epilogue, nslabs, st);

@@ -288,7 +288,7 @@ def test_w8_weight_quantisation_is_exact():
 
 @pytest.mark.parametrize("N,K", [(64, 256), (96, 4096), (40, 352), (16, 11008)])
 @pytest.mark.parametrize("outliers", [False, True])
-@pytest.mark.parametrize("M", [1, 3])
+@pytest.mark.parametrize("M", [1, 3, 9, 70])  # 9 and 70 rows: the int8 MFMA GEMM (when K is a multiple of 64), else the GEMV per row
 def test_w8_linear_matches_oracle(N, K, outliers, M):
     g = gen(13)
     W = (torch.randn(N, K, generator=g) * 0.02).to(BF)
