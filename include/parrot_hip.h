@@ -167,6 +167,17 @@ int parrot_embedding(const void* wte, int d, const int64_t* tokens, const int32_
 int parrot_prefetch(const void* data, int64_t bytes, int workgroups, void* stream);
 /* greedy step of generate() (generate/base.py:136-153 with top_k=1):
  * tokens[*pos + 1] = argmax(logits) (lowest index on ties); then *pos += 1.          */
+/* ---- GPTQ quantiser, the column loop of one 128-column block (quantize/gptq.py:397-431) -------------------------
+ * W: fp32 [rows][ldw] working copy of the weights (updated in place inside the block), Hinv: fp32 upper Cholesky factor
+ * of the inverse Hessian [cols][ldh], Q: fp32 [rows][ldq] receives the values on the grid, Err: fp32 [rows][128] the
+ * scaled errors for the caller's trailing update W[:, behind] -= Err @ Hinv[block, behind].  groupsize 0: the grid
+ * parameters scales/zeros[row*ngroups + 0] are given (per-channel); else a divisor of 128: recomputed at every group start
+ * from the current columns (find_params_weight, :317-347) and stored (round_bf16: the scale is rounded to bf16 first, the
+ * precision it is stored with in a bf16 checkpoint).  loss_rows: fp32 [rows], += the row's loss.                       */
+int parrot_gptq_block(void* W, int ldw, int rows, int col0, int ncols, const void* Hinv, int ldh, void* Q, int ldq,
+                      void* Err, void* scales, void* zeros, int ngroups, int groupsize, int maxq, int round_bf16,
+                      void* loss_rows, void* stream);
+
 /* Chat loop (chat/base.py:80-87): after a sampling step wrote tokens[*pos], latch the first stop sequence that the generated
  * tokens end with.  stop_flat: the sequences back to back (int64), stop_off: n_stop + 1 offsets, longest: the longest
  * sequence (the reference's look-back buffer: nothing matches before `longest` tokens were generated), first_gen: device

@@ -89,6 +89,7 @@ SIGNATURES = {
     "parrot_pk_step": (_i, [C.POINTER(PkState), _vp]),
     "parrot_embedding": (_i, [_vp, _i, _vp, _vp, _i, _vp, _i, _vp]),
     "parrot_prefetch": (_i, [_vp, _i64, _i, _vp]),
+    "parrot_gptq_block": (_i, [_vp, _i, _i, _i, _i, _vp, _i, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
     "parrot_stop_check": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp]),
     "parrot_argmax_advance": (_i, [_vp, _i, _vp, _vp, _vp]),
 }

@@ -68,6 +68,7 @@ enum KernelId : int {
     K_PK_TOKEN,
     K_PREFETCH,
     K_STOP_CHECK,
+    K_GPTQ_BLOCK,
     K_COUNT
 };
 

@@ -140,3 +140,119 @@ def rtn_quantize(weight: torch.Tensor, tile_cols: int = 128, bits: int = 4) -> T
 def pack_nibbles(q: torch.Tensor) -> torch.Tensor:
     """(out, in) uint8 values 0..15 -> the reference's quant_weight tensor: (out, in/2) with strides (1, out)."""
     return (q[:, 0::2] | (q[:, 1::2] << 4)).t().contiguous().t()
+
+
+# ------------------------------------------------------------------------------------------------ the GPTQ quantiser
+class GPTQQuantizer:
+    """Post-training int4 quantiser of one Linear with the reference's interface (quantize/gptq.py:267-444; the algorithm is
+    Frantar et al., arXiv:2210.17323): ``collect_input_stats`` as a forward hook accumulates the Hessian of the layer inputs,
+    ``quantize()`` returns ``(ColBlockQuantizedLinear, loss)``.
+
+    Device side: the Hessian update and the trailing update of every 128-column block are torch matmuls, the Cholesky
+    factorisations are torch.linalg; the serial column loop of a block - the part that does not map onto library calls - is
+    the HIP kernel ``parrot_gptq_block`` (one wave per output row, lanes hold the block's columns).
+    Differences from the reference, on purpose:
+      * grouped quantisation (``groupsize`` 32 / 64 / 128) works: the reference writes the per-group parameters with the wrong
+        shape and reads them from not yet compensated weights (:407-412); here they come from the current columns of the group;
+      * the grid parameters are rounded to the checkpoint dtype BEFORE the weights are put on the grid, so that the stored
+        (scales, zeros, nibbles) reproduce the quantiser's result exactly (the reference quantises with fp32 parameters and
+        stores them in the weight dtype).
+    """
+
+    def __init__(self, linear_module, *, bits, perchannel=True, sym=False, blocksize=128, percdamp=0.01, groupsize=-1,
+                 actorder=False) -> None:
+        assert isinstance(linear_module, torch.nn.Linear)
+        if bits != 4 or not perchannel or sym or blocksize != 128:
+            raise NotImplementedError("the HIP quantiser builds 4-bit asymmetric per-row grids in blocks of 128 columns")
+        if groupsize != -1 and (groupsize <= 0 or 128 % groupsize):
+            raise NotImplementedError("groupsize must be -1 or a divisor of 128")
+        assert not (actorder and groupsize != -1), "The permutation trick does not work for grouped quantization"
+        self.linear_module = linear_module
+        self.dev = linear_module.weight.device
+        if self.dev.type != "cuda":
+            raise ParrotHipError("GPTQQuantizer runs on the HIP device (no CPU fallback): move the module to cuda")
+        self.rows, self.columns = linear_module.weight.shape
+        self.H = torch.zeros((self.columns, self.columns), device=self.dev)
+        self.nsamples = 0
+        self.bits, self.maxq = bits, 2 ** bits - 1
+        self.blocksize, self.percdamp, self.groupsize, self.actorder = blocksize, percdamp, groupsize, actorder
+        self.tile_cols = self.columns if groupsize == -1 else groupsize
+
+    def collect_input_stats(self, _1, inp, _2) -> None:
+        """Running mean of 2 X^T X over the calibration batches (:349-362)."""
+        inp = inp[0].detach()
+        if inp.dim() == 2:
+            inp = inp.unsqueeze(0)
+        b = inp.shape[0]
+        rows = inp.reshape(-1, inp.shape[-1]).float()
+        self.H *= self.nsamples / (self.nsamples + b)
+        self.nsamples += b
+        rows = rows * (2 / self.nsamples) ** 0.5
+        self.H.addmm_(rows.t(), rows)
+
+    @staticmethod
+    def find_params_weight(x: torch.Tensor, maxq: int = 15) -> Tuple[torch.Tensor, torch.Tensor]:
+        """Per-row asymmetric grid whose range contains 0 (:317-347)."""
+        zero_ = torch.zeros(x.shape[0], device=x.device)
+        lo = torch.minimum(x.min(1)[0], zero_)
+        hi = torch.maximum(x.max(1)[0], zero_)
+        flat = (lo == 0) & (hi == 0)
+        lo[flat], hi[flat] = -1.0, 1.0
+        # IEEE division (torch's device division by a constant multiplies by the reciprocal: 1 ulp off the reference's CPU
+        # result): divide in float64 and round once
+        scale = ((hi - lo).double() / maxq).float()
+        zero = torch.round((-lo).double() / scale.double()).float()
+        return scale.unsqueeze(1), zero.unsqueeze(1)
+
+    @torch.no_grad()
+    def quantize(self):
+        from .. import _hip
+        from .._hip import check, ptr
+
+        lin = self.linear_module
+        wdtype = lin.weight.dtype
+        W = lin.weight.detach().to(dtype=torch.float32, copy=True).contiguous()
+        rows, cols = W.shape
+        ngroups = -(-cols // self.tile_cols)
+        scales = torch.zeros((rows, ngroups), dtype=torch.float32, device=self.dev)
+        zeros = torch.zeros_like(scales)
+        if self.groupsize == -1:
+            s, z = self.find_params_weight(W, self.maxq)
+            scales[:] = s.to(wdtype).float()  # the precision it will be stored with
+            zeros[:] = z
+        H = self.H
+        del self.H
+        dead = torch.diag(H) == 0
+        H[dead, dead] = 1
+        W[:, dead] = 0
+        perm = None
+        if self.actorder:
+            perm = torch.argsort(torch.diag(H), descending=True)
+            W = W[:, perm].contiguous()
+            H = H[perm][:, perm]
+        idx = torch.arange(cols, device=self.dev)
+        H[idx, idx] += self.percdamp * torch.mean(torch.diag(H))
+        Hinv = torch.linalg.cholesky(torch.cholesky_inverse(torch.linalg.cholesky(H)), upper=True).contiguous()
+        del H
+        Q = torch.zeros_like(W)
+        err = torch.zeros((rows, 128), dtype=torch.float32, device=self.dev)
+        loss_rows = torch.zeros((rows,), dtype=torch.float32, device=self.dev)
+        lib = _hip.load()
+        for i1 in range(0, cols, 128):
+            i2 = min(i1 + 128, cols)
+            check(lib.parrot_gptq_block(ptr(W), cols, rows, i1, i2 - i1, ptr(Hinv), cols, ptr(Q), cols, ptr(err), ptr(scales),
+                                        ptr(zeros), ngroups, 0 if self.groupsize == -1 else self.groupsize, self.maxq,
+                                        int(wdtype == torch.bfloat16), ptr(loss_rows), _hip.stream()), "parrot_gptq_block")
+            if i2 < cols:
+                W[:, i2:].addmm_(err[:, : i2 - i1], Hinv[i1:i2, i2:], alpha=-1.0)
+        if perm is not None:
+            Q = Q[:, torch.argsort(perm)]
+        error = float(loss_rows.sum())
+        q_module = ColBlockQuantizedLinear(lin.in_features, lin.out_features, lin.bias is not None, bits=self.bits,
+                                           tile_cols=self.groupsize).to(self.dev)
+        q_module.scales = scales.to(wdtype)
+        q_module.zeros = zeros.to(wdtype)
+        q_module.pack_weight(Q)
+        if lin.bias is not None:
+            q_module.bias = lin.bias.detach().clone()
+        return q_module, error

@@ -269,8 +269,45 @@ def golden_chat(ref):
     np.savez_compressed(OUT / "chat.npz", **out)
 
 
+@torch.no_grad()
+def golden_gptq_quantizer(ref):
+    """quantize/gptq.py::GPTQQuantizer (:267-444) on a small fp32 Linear with Hessians from random calibration rows:
+    per-channel (groupsize -1, the only mode of the reference that runs), with and without the activation-order trick."""
+    gptq = ref["gptq"]
+    gen = torch.Generator().manual_seed(321)
+    N, K = 48, 256
+    out = {}
+    W = torch.randn(N, K, generator=gen) * 0.02
+    W[:, 7] *= 6.0   # a few heavy columns so that the activation order differs from the natural one
+    bias = torch.randn(N, generator=gen) * 0.1
+    X = torch.randn(3, 1, 40, K, generator=gen)
+    X[..., 11] *= 5.0
+    X[..., 200] = 0.0  # a dead input column (H diagonal 0: gptq.py:378-380)
+    out["W"], out["bias"], out["X"] = f32(W), f32(bias), f32(X)
+    for actorder in (False, True):
+        lin = torch.nn.Linear(K, N, bias=True)
+        lin.weight.copy_(W)
+        lin.bias.copy_(bias)
+        qz = gptq.GPTQQuantizer(lin, bits=4, groupsize=-1, actorder=actorder)
+        for b in range(X.shape[0]):
+            qz.collect_input_stats(None, (X[b],), None)
+        if not actorder:
+            out["H"] = f32(qz.H.clone())  # (quantize() goes on to modify H in place)
+        qmod, err = qz.quantize()
+        tag = f"act{int(actorder)}"
+        out[f"{tag}_scales"], out[f"{tag}_zeros"] = f32(qmod.scales), f32(qmod.zeros)
+        out[f"{tag}_weight"] = f32(qmod.get_weight(torch.float32))
+        out[f"{tag}_qw_mem"] = qmod.quant_weight.t().contiguous().numpy()
+        out[f"{tag}_error"] = np.array(err)
+        print("gptq quantizer", tag, "error", err)
+    np.savez_compressed(OUT / "gptq_quantizer.npz", **out)
+
+
 if __name__ == "__main__":
     ref = import_reference()
+    if "--gptq-quantizer-only" in sys.argv:
+        golden_gptq_quantizer(ref)
+        sys.exit(0)
     if "--chat-only" in sys.argv:
         golden_chat(ref)
         sys.exit(0)
@@ -279,3 +316,4 @@ if __name__ == "__main__":
     golden_models(ref)
     golden_generate(ref)
     golden_chat(ref)
+    golden_gptq_quantizer(ref)

@@ -195,3 +195,24 @@ def test_chat_generator_matches_the_reference_stream(golden_dir, case):
            for y in oc.generate(model, torch.from_numpy(g["prompt"]), int(g["max_returned"]), int(g["max_returned"]),
                                 temperature=1.0, top_k=1, stop_tokens=stops)]
     assert got == want
+
+
+@pytest.mark.parametrize("actorder", [False, True])
+def test_gptq_quantizer_matches_the_reference(golden_dir, actorder):
+    """oracle/gptq.py against the reference's GPTQQuantizer (fp32, per-channel): Hessian, grid parameters and loss to fp32
+    round-off; the quantised weights identical except where a value sits on a rounding boundary of the grid (the two
+    implementations order their fp32 sums differently) - there by exactly one grid step."""
+    from oracle import gptq as og
+
+    g = np.load(golden_dir / "gptq_quantizer.npz")
+    W, X = torch.from_numpy(g["W"]), torch.from_numpy(g["X"])
+    H = og.hessian_from([X[b] for b in range(X.shape[0])])
+    assert torch.allclose(H, torch.from_numpy(g["H"]), rtol=1e-5, atol=1e-6)
+    Q, s, z, loss = og.quantize(W, H, actorder=actorder)
+    tag = f"act{int(actorder)}"
+    assert torch.equal(s, torch.from_numpy(g[f"{tag}_scales"])) and torch.equal(z, torch.from_numpy(g[f"{tag}_zeros"]))
+    ref = torch.from_numpy(g[f"{tag}_weight"])
+    d = (Q - ref).abs()
+    assert float((d == 0).float().mean()) >= 0.998
+    assert float((d / s).max()) <= 1.0 + 1e-4  # never more than one grid step
+    assert abs(loss - float(g[f"{tag}_error"])) <= 1e-4 * float(g[f"{tag}_error"])
