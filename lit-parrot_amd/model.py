@@ -132,10 +132,23 @@ def _fused_norm(mod: Optional[nn.Module]) -> Optional[ops.Norm]:
     raise ParrotHipError(f"no HIP kernel for norm class {type(mod).__name__}")
 
 
+# Calibration (quantize/gptq.py::blockwise_quantization): id(Linear) -> callable(rows) that receives the rows the Linear is
+# applied to.  The fused pipeline never materialises a normalised activation, so when a Linear is observed its input norm is
+# run as a stand-alone kernel first (the reference hooks ``module.forward`` instead, quantize/gptq.py:500).
+LINEAR_OBSERVERS: dict = {}
+
+
 def _linear(mod: nn.Module, x: torch.Tensor, out: torch.Tensor, *, epilogue: int = EPI_NONE, residual=None,
             partner: Optional[nn.Module] = None, norm: Optional[nn.Module] = None) -> torch.Tensor:
     """Run one Linear-shaped module on rows with a fused epilogue — and optionally the norm module in front of it
     fused as a prologue — whatever class ``quantization()`` installed."""
+    if LINEAR_OBSERVERS and (id(mod) in LINEAR_OBSERVERS or (partner is not None and id(partner) in LINEAR_OBSERVERS)):
+        if norm is not None:
+            x = _norm(norm, x, torch.empty_like(x))
+            norm = None
+        for m in (mod, partner):
+            if m is not None and id(m) in LINEAR_OBSERVERS:
+                LINEAR_OBSERVERS[id(m)](x)
     norm = _fused_norm(norm)
     if _ACTIVE_PREFETCHER is not None and x.shape[0] == 1:
         _ACTIVE_PREFETCHER.before(mod)

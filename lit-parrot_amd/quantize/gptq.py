@@ -256,3 +256,74 @@ class GPTQQuantizer:
         if lin.bias is not None:
             q_module.bias = lin.bias.detach().clone()
         return q_module, error
+
+
+@torch.no_grad()
+def blockwise_quantization(model, sample_inputs: torch.Tensor, working_device=None, *, bits: int = 4, groupsize: int = -1,
+                           verbose: bool = False):
+    """Classic post-training quantisation of every Linear of ``model`` in order (quantize/gptq.py:461-548): each Linear sees
+    the outputs of the already quantised layers in front of it.  ``sample_inputs``: (n_samples, T) token ids.  The model is a
+    ``lit_parrot_amd.GPT`` with dense bf16 Linears on the HIP device (``working_device`` is accepted for interface parity; the
+    whole model stays resident: 288 GB of HBM).  Returns {layer name: GPTQ loss}."""
+    from .. import model as model_mod
+
+    dev = model.transformer.wte.weight.device
+    if dev.type != "cuda":
+        raise ParrotHipError("blockwise_quantization runs on the HIP device: move the model to cuda")
+    sample_inputs = sample_inputs.to(dev)
+    n, T = sample_inputs.shape
+    inps = model.transformer.wte(sample_inputs)
+    outs = torch.zeros_like(inps)
+    cos, sin = model.build_rope_cache(sample_inputs)
+    rope = (cos[:T].contiguous(), sin[:T].contiguous())
+    # fc_1 and fc_2 of a SwiGLU MLP read the same rows (neither sees the other's output), so they are observed in one pass
+    # and replaced together - the fused SwiGLU launch needs both weights in the same format
+    names = [("attn.attn",), ("attn.proj",)]
+    names += [("mlp.fc",)] if model.config._mlp_class == "GptNeoxMLP" else [("mlp.fc_1", "mlp.fc_2")]
+    names += [("mlp.proj",)]
+    losses = {}
+
+    def run_block(block):
+        for j in range(n):
+            outs[j: j + 1], _ = block(inps[j: j + 1], rope, model.config.block_size)
+
+    def quantise(targets, run):
+        """targets: [(parent module, attribute, label)] observed in ONE run of ``run`` and then replaced."""
+        quantizers = []
+        for parent, attr, label in targets:
+            module = getattr(parent, attr)
+            gptq = GPTQQuantizer(module, bits=bits, groupsize=groupsize, actorder=(groupsize == -1))
+            model_mod.LINEAR_OBSERVERS[id(module)] = (lambda q: lambda rows: q.collect_input_stats(None, (rows.unsqueeze(0),), None))(gptq)
+            quantizers.append((parent, attr, label, module, gptq))
+        try:
+            run()
+        finally:
+            for _, _, _, module, _ in quantizers:
+                model_mod.LINEAR_OBSERVERS.pop(id(module), None)
+        for parent, attr, label, _, gptq in quantizers:
+            q_module, error = gptq.quantize()
+            setattr(parent, attr, q_module)
+            losses[label] = error
+            if verbose:
+                print(f"{label}: quantization error {error:.1f}", flush=True)
+
+    for i, block in enumerate(model.transformer.h):
+        for group in names:
+            targets = []
+            for name in group:
+                pname, dname = name.rsplit(".", 1)
+                targets.append((block.get_submodule(pname), dname, f"transformer.h.{i}.{name}"))
+            quantise(targets, lambda: run_block(block))
+        run_block(block)  # the quantised block's outputs are the next block's inputs
+        inps, outs = outs, inps
+    # lm_head sees the final norm's output (the fused pipeline applies ln_f inside the lm_head launch)
+    hidden = inps
+
+    def run_head():
+        for j in range(n):
+            x = hidden[j]
+            ws_out = torch.empty((x.shape[0], model.config.padded_vocab_size), dtype=x.dtype, device=dev)
+            model_mod._linear(model.lm_head, x.contiguous(), ws_out, norm=model.transformer.ln_f)
+
+    quantise([(model, "lm_head", "lm_head")], run_head)
+    return losses
