@@ -89,6 +89,23 @@ int parrot_w4_gemm(const void* packed, const void* packed2, const void* x, int l
                    int K, int group, int epilogue, const parrot_norm_t* norm, void* workspace,
                    void* stream);
 
+/* ---- 4-bit codebook weights: bitsandbytes NF4 / FP4 (reference quantize/bnb.py:62-75 `Linear4bit`, selected by
+ * lit_gpt/utils.py:36-68 "bnb.nf4", "bnb.nf4-dq", "bnb.fp4", "bnb.fp4-dq") ----------------------------------------
+ * bitsandbytes format: flat row-major uint8, two weights per byte (FIRST weight in the HIGH nibble), one fp32 absmax per
+ * block of 64 consecutive weights, w = code[q] * absmax with a 16-entry codebook.  Kernel-native format: W4K records
+ *  with group = block and the group metadata word = the block's fp32 absmax; built with parrot_w4_repack
+ * from the nibbles re-laid as (N, K/2) strides (1, N) low-nibble-first and the absmax words split into two 16-bit halves
+ * (scales = low half, zeros = high half).  With compress_statistics ("-dq") the host de-nests absmax to fp32 first.
+ * parrot_w4c_gemv replaces bnb.matmul_4bit for M <= 8 rows (same epilogues / fused norm as parrot_w4_gemv);
+ * code16_bf16 = the codebook rounded to bf16, one value per 32-bit word (bf16 bits in the low half; 16 words, device).
+ * parrot_w4c_dequant replaces bnb.functional.dequantize_4bit: out (N, K) bf16 = bf16(code16_f32[q] * absmax); the
+ * prefill multiplies it with parrot_bf16_gemm (bitsandbytes' own MatMul4Bit is dequantise + F.linear).            */
+int parrot_w4c_gemv(const void* packed, const void* packed2, const void* code16_bf16, const void* x, int ldx, int M,
+                    const void* bias, const void* residual, int ldr, void* out, int ldo, int N, int K, int block,
+                    int epilogue, const parrot_norm_t* norm, void* stream);
+int parrot_w4c_dequant(const void* packed, const void* code16_f32, void* out, int ldo, int N, int K, int block,
+                       void* stream);
+
 /* ---- dense bf16 Linear (torch.nn.Linear on the bf16 path, lit_gpt/model.py:29,188,190,281-295)
  * W is (N, K) row-major bf16.                                                    */
 int parrot_bf16_gemv(const void* W, const void* W2, const void* x, int ldx, int M, const void* bias,

@@ -69,6 +69,9 @@ enum KernelId : int {
     K_PREFETCH,
     K_STOP_CHECK,
     K_GPTQ_BLOCK,
+    K_W4C_GEMV,
+    K_W4C_GEMV_DUAL,
+    K_W4C_DEQUANT,
     K_COUNT
 };
 

@@ -112,12 +112,19 @@ static unsigned long long* g_w4_dbg_host = nullptr;  // set by parrot_tune_w4_st
 // sizes the grid to what is resident at once, so that no workgroup starts late and pays the activation / norm chain
 // behind everybody else's weight stream (measured on lm_head: a 4th-round workgroup entered at +11 us and had its norm
 // ready 6.5 us later).  MAXW = waves the build allows (8 -> 256 VGPRs, 16 -> 128).
-template <int M, bool DUAL, int RU, int MAXW>
+//
+// CB = true: the nibbles index a 16-entry codebook (bitsandbytes NF4 / FP4, quantize/bnb.py:62-75) and the group metadata
+// word is the block's fp32 absmax: y = sum over blocks of absmax * sum_k x[k] * code[q[k]].  The codebook (bf16) is
+// spread over LDS as one private column per lane (entry e of lane l at byte e * 256 + l * 4: every lane stays in its own
+// bank, no conflicts whatever the indices are); a weight pair is fetched with two 16-bit LDS reads into the halves of one
+// register, which is the operand of the same v_dot2 as the affine path.
+template <int M, bool DUAL, int RU, int MAXW, bool CB>
 __global__ void __launch_bounds__(MAXW * 64)
 w4_gemv_kernel(const uint4* __restrict__ W, const uint4* __restrict__ W2, const bf16_t* __restrict__ x, int ldx,
                const bf16_t* __restrict__ bias, const bf16_t* residual, int ldr, bf16_t* out, int ldo, int N, int K,
-               int wps, int epi, int iters, NormArgs na, W4Plan plan, unsigned long long* dbg) {
+               int wps, int epi, int iters, NormArgs na, W4Plan plan, unsigned long long* dbg, const uint32_t* __restrict__ code) {
     constexpr int NW = DUAL ? 2 : 1;
+    __shared__ __attribute__((aligned(4096))) uint32_t cbt[CB ? 16 * 64 : 1];
     extern __shared__ __attribute__((aligned(16))) unsigned char w4_smem[];  // normalised activations [M][K] bf16 (norm only)
     __shared__ float red[2][MAXW][RU * M * NW];  // double-buffered over the batches: one barrier per batch
     __shared__ float stat[16];
@@ -182,6 +189,9 @@ w4_gemv_kernel(const uint4* __restrict__ W, const uint4* __restrict__ W2, const 
         }
     }
 
+    if constexpr (CB) {  // entry e is wave-uniform: scalar loads (their own counter, nothing waits for vector memory here)
+        for (int e = wave; e < 16; e += nwaves) cbt[e * 64 + lane] = code[e];
+    }
     uint4 w[NW][RU];
     uint32_t mt[NW][RU];
     // Rolling window of weight loads.  A CU accepts only so many vector-memory instructions in flight; a wave that issues
@@ -278,10 +288,17 @@ w4_gemv_kernel(const uint4* __restrict__ W, const uint4* __restrict__ W2, const 
 #pragma unroll
     for (int m = 0; m < M; ++m) {
         float s = 0.f;
+        if constexpr (!CB) {
 #pragma unroll
-        for (int i = 0; i < 16; ++i) s += bflo(xr[m][i]) + bfhi(xr[m][i]);
+            for (int i = 0; i < 16; ++i) s += bflo(xr[m][i]) + bfhi(xr[m][i]);
+        }
         xs[m] = s;
     }
+    if constexpr (CB) __syncthreads();  // codebook columns written (the norm path's barrier lies before on its own branch only)
+    // LDS byte address of this lane's codebook column; the table must start on a 4-KB boundary so that the lookups can
+    // write "nibble" into byte 1 of the address: the table must lie at LDS offset 0 (it is the most-aligned LDS variable of the kernel)
+    const uint32_t cb_col = (uint32_t)(uintptr_t)cbt + lane * 4;
+    if (CB && ((uint32_t)(uintptr_t)cbt & 0xFFFFu) != 0) __builtin_trap();  // folded away: the most-aligned LDS variable is placed at 0
     w4_stamp(dbg, 1);
     __builtin_amdgcn_s_setprio(0);
 
@@ -320,15 +337,21 @@ w4_gemv_kernel(const uint4* __restrict__ W, const uint4* __restrict__ W2, const 
             float part[NW][M];
 #pragma unroll
             for (int q = 0; q < NW; ++q) {
-                const float s = bflo(mt[q][u]);
-                const float zz = 128.0f + bfhi(mt[q][u]);
+                const float s = CB ? __uint_as_float(mt[q][u]) : bflo(mt[q][u]);
+                const float zz = CB ? 0.f : 128.0f + bfhi(mt[q][u]);
+                uint32_t wcb[16];
+                if constexpr (CB) w4c_slice_lookup(w[q][u], cb_col, wcb);  // once per weight row, shared by the M input rows
 #pragma unroll
                 for (int m = 0; m < M; ++m) {
-                    const float p = w4_slice_dot(w[q][u], xr[m]);
-                    if constexpr (kSum8)
-                        lanep[q][u & 7] = s * (p - zz * xs[m]);  // all eight rows are reduced together after the batch
+                    float v;
+                    if constexpr (CB)
+                        v = s * w4c_pairs_dot(wcb, xr[m]);
                     else
-                        part[q][m] = wave_sum_to_lane63(s * (p - zz * xs[m]));
+                        v = s * (w4_slice_dot(w[q][u], xr[m]) - zz * xs[m]);
+                    if constexpr (kSum8)
+                        lanep[q][u & 7] = v;  // all eight rows are reduced together after the batch
+                    else
+                        part[q][m] = wave_sum_to_lane63(v);
                 }
             }
             if constexpr (!kSum8) {
@@ -573,10 +596,10 @@ static int pick_wps(int N, int RU, int nslabs, int maxw, bool norm) {
     return wps;
 }
 
-template <int M, bool DUAL, int RU, int MAXW>
+template <int M, bool DUAL, int RU, int MAXW, bool CB>
 static int w4_gemv_launch_v(const void* packed, const void* packed2, const void* x, int ldx, const void* bias,
                             const void* residual, int ldr, void* out, int ldo, int N, int K, int epi, const NormArgs& na,
-                            const W4Plan& plan, hipStream_t st) {
+                            const W4Plan& plan, hipStream_t st, const void* code) {
     const int wps = pick_wps(N, RU, plan.nslabs, MAXW, na.kind != 0);
     const int R = wps * RU;
     const int nthreads = 64 * plan.nslabs * wps;
@@ -592,9 +615,11 @@ static int w4_gemv_launch_v(const void* packed, const void* packed2, const void*
     if (g_resident_override > 0) resident = g_resident_override;
     const int iters = (batches + resident - 1) / resident;
     const dim3 grid((batches + iters - 1) / iters), block(nthreads);
-    return launch(DUAL ? K_W4_GEMV_DUAL : K_W4_GEMV, w4_gemv_kernel<M, DUAL, RU, MAXW>, grid, block, lds, st,
+    return launch(CB ? (DUAL ? K_W4C_GEMV_DUAL : K_W4C_GEMV) : (DUAL ? K_W4_GEMV_DUAL : K_W4_GEMV),
+                  w4_gemv_kernel<M, DUAL, RU, MAXW, CB>, grid, block, lds, st,
                   (const uint4*)packed, (const uint4*)packed2, (const bf16_t*)x, ldx, (const bf16_t*)bias,
-                  (const bf16_t*)residual, ldr, (bf16_t*)out, ldo, N, K, wps, epi, iters, na, plan, g_w4_dbg_host);
+                  (const bf16_t*)residual, ldr, (bf16_t*)out, ldo, N, K, wps, epi, iters, na, plan, g_w4_dbg_host,
+                  (const uint32_t*)code);
 }
 
 static int g_use_stream = 0;  // the pipelined kernel measured no faster than the burst kernel (tools/microbench.py); kept selectable
@@ -620,11 +645,11 @@ static int w4_stream_launch(const void* packed, const void* packed2, const void*
                   (bf16_t*)out, N, K, wps, epi, na, plan);
 }
 
-template <int M>
+template <int M, bool CB>
 static int w4_gemv_launch(const void* packed, const void* packed2, const void* x, int ldx, const void* bias,
                           const void* residual, int ldr, void* out, int ldo, int N, int K, int epi, const NormArgs& na,
-                          const W4Plan& plan, hipStream_t st) {
-    if (M == 1 && g_use_stream) {
+                          const W4Plan& plan, hipStream_t st, const void* code) {
+    if (M == 1 && g_use_stream && !CB) {
         const bool dual = epi == PARROT_EPI_SWIGLU;
         if (plan.nslabs <= 8)
             return dual ? w4_stream_launch<true, 4, 8>(packed, packed2, x, bias, residual, out, N, K, epi, na, plan, st)
@@ -636,7 +661,7 @@ static int w4_gemv_launch(const void* packed, const void* packed2, const void* x
     constexpr int RU1 = (M == 1) ? 8 : 4;  // (16 / 8 rows in flight measured slower: occupancy drops to 3 waves per SIMD)
     constexpr int RU2 = (M == 1) ? 8 : ((M <= 2) ? 4 : 2);  // M = 1: 8 rows x 2 weights per wave measured 3 % faster end to end than 4
 #define PARROT_W4_GO(DUALV, RUV, MAXWV) \
-    return w4_gemv_launch_v<M, DUALV, RUV, MAXWV>(packed, packed2, x, ldx, bias, residual, ldr, out, ldo, N, K, epi, na, plan, st)
+    return w4_gemv_launch_v<M, DUALV, RUV, MAXWV, CB>(packed, packed2, x, ldx, bias, residual, ldr, out, ldo, N, K, epi, na, plan, st, code)
     if (plan.nslabs <= 8) {
         if (epi == PARROT_EPI_SWIGLU) PARROT_W4_GO(true, RU2, 8);
         // small single-row launches (the attention out-projection: N x slabs <= 16 K): 4 rows per wave, twice the waves -
@@ -647,6 +672,68 @@ static int w4_gemv_launch(const void* packed, const void* packed2, const void* x
     if (epi == PARROT_EPI_SWIGLU) PARROT_W4_GO(true, 2, 16);
     PARROT_W4_GO(false, 4, 16);
 #undef PARROT_W4_GO
+}
+
+template <bool CB>
+static int w4_gemv_entry(const char* who, const void* packed, const void* packed2, const void* code, const void* x, int ldx, int M,
+                         const void* bias, const void* residual, int ldr, void* out, int ldo, int N, int K, int group,
+                         int epilogue, const parrot_norm_t* norm, void* stream) {
+    int rc = check_linear_args(who, packed, packed2, x, ldx, M, residual, ldr, out, ldo, N, K, epilogue);
+    if (rc != PARROT_OK) return rc;
+    PARROT_UNSUPPORTED(!(epilogue == PARROT_EPI_SWIGLU && bias), "%s: SWIGLU epilogue takes no bias", who);
+    W4Plan plan;
+    rc = w4_make_plan(N, K, group, &plan);
+    if (rc != PARROT_OK) return rc;
+    NormArgs na;
+    rc = make_norm_args(norm, K, &na);
+    if (rc != PARROT_OK) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    const bf16_t* xb = (const bf16_t*)x;
+    const bf16_t* rb = (const bf16_t*)residual;
+    bf16_t* ob = (bf16_t*)out;
+    for (int m0 = 0; m0 < M; m0 += 4) {
+        const int mm = (M - m0 < 4) ? M - m0 : 4;
+        const void* xm = xb + (int64_t)m0 * ldx;
+        const void* rm = rb ? rb + (int64_t)m0 * ldr : nullptr;
+        void* om = ob + (int64_t)m0 * ldo;
+        switch (mm) {
+            case 1: rc = w4_gemv_launch<1, CB>(packed, packed2, xm, ldx, bias, rm, ldr, om, ldo, N, K, epilogue, na, plan, st, code); break;
+            case 2: rc = w4_gemv_launch<2, CB>(packed, packed2, xm, ldx, bias, rm, ldr, om, ldo, N, K, epilogue, na, plan, st, code); break;
+            case 3: rc = w4_gemv_launch<3, CB>(packed, packed2, xm, ldx, bias, rm, ldr, om, ldo, N, K, epilogue, na, plan, st, code); break;
+            default: rc = w4_gemv_launch<4, CB>(packed, packed2, xm, ldx, bias, rm, ldr, om, ldo, N, K, epilogue, na, plan, st, code); break;
+        }
+        if (rc != PARROT_OK) return rc;
+    }
+    return PARROT_OK;
+}
+
+// Codebook weights -> dense bf16 (N, K): w = bf16(code[q] * absmax), the rounding bitsandbytes' dequantize_4bit applies before
+// the matmul (the prefill path multiplies this on the matrix cores, as the reference does: bnb MatMul4Bit = dequantise + F.linear).
+// One thread per 16-byte slice (32 weights -> 64 bytes of output).
+__global__ void __launch_bounds__(256)
+w4c_dequant_kernel(const uint4* __restrict__ W, const float* __restrict__ code, bf16_t* __restrict__ out, int ldo, int N,
+                   int slices_per_row, W4Plan plan) {
+    const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (tid >= (int64_t)N * slices_per_row) return;
+    const int o = (int)(tid / slices_per_row), t = (int)(tid % slices_per_row);
+    int c = 0;
+    while (c + 1 < plan.nslabs && t >= plan.slab[c + 1].slice0) ++c;
+    const W4Slab sl = plan.slab[c];
+    const uint4* rec = W + (int64_t)o * plan.row16;
+    const uint4 v4 = rec[sl.w_off16 + (t - sl.slice0)];
+    const float absmax = __uint_as_float(reinterpret_cast<const uint32_t*>(rec + sl.meta_off16)[t / plan.Gs - sl.g0]);
+    const uint32_t dw[4] = {v4.x, v4.y, v4.z, v4.w};
+    uint32_t o32[16];
+#pragma unroll
+    for (int d = 0; d < 4; ++d)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float lo = code[(dw[d] >> (4 * i)) & 0xFu] * absmax, hi = code[(dw[d] >> (16 + 4 * i)) & 0xFu] * absmax;
+            o32[4 * d + i] = (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16);
+        }
+    uint4* dst = reinterpret_cast<uint4*>(out + (int64_t)o * ldo + (int64_t)t * 32);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) dst[q] = make_uint4(o32[4 * q], o32[4 * q + 1], o32[4 * q + 2], o32[4 * q + 3]);
 }
 
 }  // namespace parrot
@@ -702,33 +789,29 @@ int parrot_w4_repack(void* quant_weight_ref, void* scales, void* zeros, int N, i
 int parrot_w4_gemv(const void* packed, const void* packed2, const void* x, int ldx, int M, const void* bias,
                    const void* residual, int ldr, void* out, int ldo, int N, int K, int group, int epilogue,
                    const parrot_norm_t* norm, void* stream) {
-    int rc = check_linear_args("w4_gemv", packed, packed2, x, ldx, M, residual, ldr, out, ldo, N, K, epilogue);
-    if (rc != PARROT_OK) return rc;
-    PARROT_UNSUPPORTED(!(epilogue == PARROT_EPI_SWIGLU && bias), "w4_gemv: SWIGLU epilogue takes no bias");
+    return w4_gemv_entry<false>("w4_gemv", packed, packed2, nullptr, x, ldx, M, bias, residual, ldr, out, ldo, N, K, group, epilogue,
+                                norm, stream);
+}
+
+int parrot_w4c_gemv(const void* packed, const void* packed2, const void* code16_bf16, const void* x, int ldx, int M,
+                    const void* bias, const void* residual, int ldr, void* out, int ldo, int N, int K, int block,
+                    int epilogue, const parrot_norm_t* norm, void* stream) {
+    PARROT_REQUIRE(code16_bf16 != nullptr, "w4c_gemv: codebook pointer is null");
+    return w4_gemv_entry<true>("w4c_gemv", packed, packed2, code16_bf16, x, ldx, M, bias, residual, ldr, out, ldo, N, K, block,
+                               epilogue, norm, stream);
+}
+
+int parrot_w4c_dequant(const void* packed, const void* code16_f32, void* out, int ldo, int N, int K, int block, void* stream) {
+    PARROT_REQUIRE(packed && code16_f32 && out, "w4c_dequant: null pointer");
+    PARROT_REQUIRE(ldo >= K && ldo % 8 == 0 && aligned16(out) && aligned16(packed), "w4c_dequant: out must be 16-byte aligned rows, ldo >= K");
     W4Plan plan;
-    rc = w4_make_plan(N, K, group, &plan);
+    const int rc = w4_make_plan(N, K, block, &plan);
     if (rc != PARROT_OK) return rc;
-    NormArgs na;
-    rc = make_norm_args(norm, K, &na);
-    if (rc != PARROT_OK) return rc;
-    hipStream_t st = (hipStream_t)stream;
-    const bf16_t* xb = (const bf16_t*)x;
-    const bf16_t* rb = (const bf16_t*)residual;
-    bf16_t* ob = (bf16_t*)out;
-    for (int m0 = 0; m0 < M; m0 += 4) {
-        const int mm = (M - m0 < 4) ? M - m0 : 4;
-        const void* xm = xb + (int64_t)m0 * ldx;
-        const void* rm = rb ? rb + (int64_t)m0 * ldr : nullptr;
-        void* om = ob + (int64_t)m0 * ldo;
-        switch (mm) {
-            case 1: rc = w4_gemv_launch<1>(packed, packed2, xm, ldx, bias, rm, ldr, om, ldo, N, K, epilogue, na, plan, st); break;
-            case 2: rc = w4_gemv_launch<2>(packed, packed2, xm, ldx, bias, rm, ldr, om, ldo, N, K, epilogue, na, plan, st); break;
-            case 3: rc = w4_gemv_launch<3>(packed, packed2, xm, ldx, bias, rm, ldr, om, ldo, N, K, epilogue, na, plan, st); break;
-            default: rc = w4_gemv_launch<4>(packed, packed2, xm, ldx, bias, rm, ldr, om, ldo, N, K, epilogue, na, plan, st); break;
-        }
-        if (rc != PARROT_OK) return rc;
-    }
-    return PARROT_OK;
+    const int64_t total = (int64_t)N * (K / 32);
+    const int64_t blocks = (total + 255) / 256;
+    PARROT_UNSUPPORTED(blocks < (1ll << 31), "w4c_dequant: matrix too large");
+    return launch(K_W4C_DEQUANT, w4c_dequant_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const uint4*)packed,
+                  (const float*)code16_f32, (bf16_t*)out, ldo, N, K / 32, plan);
 }
 
 }  // extern "C"

@@ -88,4 +88,48 @@ __device__ __forceinline__ float w4_slice_dot(const uint4 w, const uint32_t (&xr
     return p0 + p1;
 }
 
+// Codebook weights (NF4 / FP4): the 32 nibbles of a slice -> 16 bf16 pairs {code[q[2j]], code[q[2j+1]]} through the lane's
+// private codebook column in LDS (cb_col = table + lane * 4, entry e at byte e * 256).  Nibble order inside a dword as in
+// W4K: bits 4i <-> k = 8d + 2i, bits 16 + 4i <-> k = 8d + 2i + 1.
+// One instruction per address: v_and_b32_sdwa takes byte b of the (possibly >> 4) weight dword, masks the nibble and writes
+// it into byte 1 of an address register whose byte 0 permanently holds lane * 4 (dst_unused:UNUSED_PRESERVE), i.e.
+// address = nibble * 256 + lane * 4.  ds_read_u16_d16 / _d16_hi deposit the two codebook values of a pair in the halves of
+// one register.  The compiler does not track LDS reads issued from inline asm: the caller waits with w4c_wait().
+#define W4C_PAIR(P, A, SRC_LO, SEL_LO, SRC_HI, SEL_HI)                                                              \
+    asm volatile("v_and_b32_sdwa %1, 15, %2 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:" SEL_LO "\n\t" \
+                 "ds_read_u16_d16 %0, %1\n\t"                                                                       \
+                 "v_and_b32_sdwa %1, 15, %3 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:" SEL_HI "\n\t" \
+                 "ds_read_u16_d16_hi %0, %1"                                                                         \
+                 : "=&v"(P), "+v"(A)                                                                                 \
+                 : "v"(SRC_LO), "v"(SRC_HI)                                                                          \
+                 : "memory")
+__device__ __forceinline__ void w4c_slice_lookup(const uint4 w, uint32_t cb_addr, uint32_t (&pairs)[16]) {
+    const uint32_t dw[4] = {w.x, w.y, w.z, w.w};
+    uint32_t a0 = cb_addr, a1 = cb_addr;  // byte 0 = lane * 4 (+ table base), byte 1 is rewritten per lookup
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+        const uint32_t lo4 = dw[d], hi4 = dw[d] >> 4;
+        W4C_PAIR(pairs[4 * d + 0], a0, lo4, "BYTE_0", lo4, "BYTE_2");
+        W4C_PAIR(pairs[4 * d + 1], a1, hi4, "BYTE_0", hi4, "BYTE_2");
+        W4C_PAIR(pairs[4 * d + 2], a0, lo4, "BYTE_1", lo4, "BYTE_3");
+        W4C_PAIR(pairs[4 * d + 3], a1, hi4, "BYTE_1", hi4, "BYTE_3");
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)"
+                 : "+v"(pairs[0]), "+v"(pairs[1]), "+v"(pairs[2]), "+v"(pairs[3]), "+v"(pairs[4]), "+v"(pairs[5]), "+v"(pairs[6]),
+                   "+v"(pairs[7]), "+v"(pairs[8]), "+v"(pairs[9]), "+v"(pairs[10]), "+v"(pairs[11]), "+v"(pairs[12]),
+                   "+v"(pairs[13]), "+v"(pairs[14]), "+v"(pairs[15])
+                 :
+                 : "memory");
+}
+#undef W4C_PAIR
+__device__ __forceinline__ float w4c_pairs_dot(const uint32_t (&pairs)[16], const uint32_t (&xr)[16]) {
+    float p0 = 0.f, p1 = 0.f;
+#pragma unroll
+    for (int j = 0; j < 16; j += 2) {
+        p0 = dot2_bf16(pairs[j], xr[j], p0);
+        p1 = dot2_bf16(pairs[j + 1], xr[j + 1], p1);
+    }
+    return p0 + p1;
+}
+
 }  // namespace parrot

@@ -303,8 +303,50 @@ def golden_gptq_quantizer(ref):
     np.savez_compressed(OUT / "gptq_quantizer.npz", **out)
 
 
+@torch.no_grad()
+def golden_convert(ref):
+    """scripts/convert_hf_checkpoint.py: the three copy functions on synthetic HF-named state dicts of tiny shapes (regenerated
+    from a seed in the tests).  The conversion only renames tensors and permutes rows, so the expected lit-side state dict is
+    stored as {family|lit name: sha256 of the fp16 bytes} plus {family|lit name|shape}: exact, and a few KB."""
+    import hashlib
+    import importlib.util
+
+    spec = importlib.util.spec_from_file_location("ref_convert", str(REFERENCE / "scripts" / "convert_hf_checkpoint.py"))
+    conv = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(conv)
+    from lit_parrot_amd.checkpoint import synthetic_hf_state_dict
+    from lit_parrot_amd.config import name_to_config
+
+    out = {}
+    for family, cfg_name in (("llama", "tiny-llama-gqa"), ("falcon-7b", "tiny-falcon-mqa"), ("falcon-40b", "tiny-falcon-gqa"), ("neox", "tiny-neox")):
+        cfg = ref["Config"](**dict(name_to_config[cfg_name]))
+        hf = synthetic_hf_state_dict(family, name_to_config[cfg_name], seed=77)
+        sd = {}
+        if family == "llama":
+            # two shards, q/k/v of layer 1 split across them (convert_hf_checkpoint.py keeps the holder between files)
+            names = list(hf)
+            cut = next(i for i, n in enumerate(names) if n.startswith("model.layers.1.self_attn.k_proj"))
+            holder = {}
+            conv.copy_weights_hf_llama(cfg, holder, sd, {n: hf[n] for n in names[:cut]})
+            conv.copy_weights_hf_llama(cfg, holder, sd, {n: hf[n] for n in names[cut:]})
+            assert not holder
+        elif family.startswith("falcon"):
+            conv.copy_weights_falcon("40b" if family == "falcon-40b" else "7b", sd, hf)
+        else:
+            conv.copy_weights_gpt_neox(sd, hf)
+        for k, v in sd.items():
+            a = np.ascontiguousarray(v.to(torch.float16).numpy())
+            out[f"{family}|{k}"] = np.frombuffer(hashlib.sha256(a.tobytes()).digest(), dtype=np.uint8)
+            out[f"{family}|{k}|shape"] = np.asarray(a.shape, dtype=np.int64)
+        print("convert", family, len(hf), "->", len(sd), "tensors")
+    np.savez_compressed(OUT / "convert_hf.npz", **out)
+
+
 if __name__ == "__main__":
     ref = import_reference()
+    if "--convert-only" in sys.argv:
+        golden_convert(ref)
+        sys.exit(0)
     if "--gptq-quantizer-only" in sys.argv:
         golden_gptq_quantizer(ref)
         sys.exit(0)
@@ -317,3 +359,4 @@ if __name__ == "__main__":
     golden_generate(ref)
     golden_chat(ref)
     golden_gptq_quantizer(ref)
+    golden_convert(ref)
