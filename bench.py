@@ -37,6 +37,7 @@ WORKLOADS = {
     # name: (config, quantization mode, prompt length, kv window, dtype label)
     "llama2-7b-int4": ("Llama-2-7b-hf", "gptq.int4-g128", 128, "u4 weights, bf16 activations, fp32 accumulate"),
     "llama2-7b-int8": ("Llama-2-7b-hf", "bnb.int8", 128, "int8"),
+    "llama2-7b-nf4": ("Llama-2-7b-hf", "bnb.nf4", 128, "nf4 weights (16-entry codebook), bf16 activations, fp32 accumulate"),
     "stablelm-3b-bf16": ("stablelm-base-alpha-3b", None, 512, "bf16"),
     "falcon-40b-int4": ("falcon-40b", "gptq.int4-g128", 128, "u4 weights, bf16 activations, fp32 accumulate"),
     "pythia-160m-bf16": ("pythia-160m", None, 128, "bf16"),
@@ -56,6 +57,8 @@ def linear_bytes(cfg, mode):
             out[name] = n * k // 2 + n * (-(-k // group)) * 4  # packed nibbles + bf16 scale + bf16 zero per group
         elif mode == "bnb.int8":
             out[name] = n * k + n * 4  # int8 + fp32 SCB per row
+        elif mode.startswith(("bnb.nf4", "bnb.fp4")):
+            out[name] = n * k // 2 + n * (k // 64) * 4  # packed nibbles + fp32 absmax per block of 64
         else:
             raise ValueError(mode)
     return out
@@ -72,7 +75,7 @@ def kernel_bytes_per_token(cfg, mode):
     """Algorithmic bytes handled by each kernel id of the library during one token (for the roofline object)."""
     lb = linear_bytes(cfg, mode)
     L = cfg.n_layer
-    prefix = {None: "bf16_gemv", "bnb.int8": "w8_gemv"}.get(mode, "w4_gemv")
+    prefix = {None: "bf16_gemv", "bnb.int8": "w8_gemv"}.get(mode, "w4c_gemv" if (mode or "").startswith(("bnb.nf4", "bnb.fp4")) else "w4_gemv")
     single = [k for k in lb if k not in ("mlp.fc_1", "mlp.fc_2", "lm_head")]
     res = {prefix: (sum(lb[k] for k in single) * L + lb["lm_head"], len(single) * L + 1)}
     if "mlp.fc_1" in lb:
@@ -141,9 +144,9 @@ def cpu_baseline(cfg, mode, model, prompt_cpu, budget_s: float = 20.0):
 
     tile_cols = 128 if (mode or "").endswith("g128") else -1
     sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
-    if mode == "bnb.int8":
+    if mode == "bnb.int8" or (mode or "").startswith(("bnb.nf4", "bnb.fp4")):
         return {"value": None, "unit": "tokens/s", "cores": torch.get_num_threads(), "kind": "port",
-                "sample": "skipped: int8 state dict holds only quantised weights"}
+                "sample": "skipped: the state dict of this mode holds only quantised weights"}
     oracle = om.OracleGPT(cfg, sd, "gptq" if mode and mode.startswith("gptq") else "dense", tile_cols=tile_cols)
     T0 = 4
     S = T0 + 64

@@ -8,7 +8,7 @@
   pages); the reference does the same with a custom unpickler (lit_gpt/utils.py:89-225).
 * ``stream_load`` — fill a (possibly quantised) model on the HIP device tensor by tensor: a dense checkpoint going into int4
   Linears is quantised round-to-nearest on the way (or copied as is when it already holds quant_weight/scales/zeros), into
-  LLM.int8 Linears row-quantised by the HIP kernel; at no time is more than one dense matrix resident next to the model.
+  LLM.int8 Linears row-quantised by the HIP kernel, into NF4 / FP4 Linears block-quantised; at no time is more than one dense matrix resident next to the model.
 
 The renaming rules are written as (pattern, template) pairs; ``None`` drops a tensor (rotary tables, attention masks).
 """
@@ -143,7 +143,7 @@ def stream_load(model: torch.nn.Module, state_dict: Dict[str, torch.Tensor]) -> 
     """Fill ``model`` (already on the HIP device, possibly built under ``quantization(...)``) from ``state_dict`` one tensor at
     a time.  Dense ``<linear>.weight`` entries going into int4 / int8 Linears are quantised on the device on the way in.
     Returns the checkpoint keys that were not used."""
-    from .quantize.bnb import InferenceLinear8bitLt
+    from .quantize.bnb import InferenceLinear8bitLt, Linear4bit
     from .quantize.gptq import ColBlockQuantizedLinear, pack_nibbles, rtn_quantize
 
     modules = dict(model.named_modules())
@@ -161,7 +161,7 @@ def stream_load(model: torch.nn.Module, state_dict: Dict[str, torch.Tensor]) -> 
             mod.quant_weight.copy_(pack_nibbles(q))
             mod._packed = None
             del w, q, s, z
-        elif isinstance(mod, InferenceLinear8bitLt) and leaf == "weight":
+        elif isinstance(mod, (InferenceLinear8bitLt, Linear4bit)) and leaf == "weight" and value.is_floating_point():
             mod._quantize_weight(value.to(mod.weight.device))
         elif key in own:
             tgt = own[key]

@@ -116,8 +116,8 @@ static unsigned long long* g_w4_dbg_host = nullptr;  // set by parrot_tune_w4_st
 // CB = true: the nibbles index a 16-entry codebook (bitsandbytes NF4 / FP4, quantize/bnb.py:62-75) and the group metadata
 // word is the block's fp32 absmax: y = sum over blocks of absmax * sum_k x[k] * code[q[k]].  The codebook (bf16) is
 // spread over LDS as one private column per lane (entry e of lane l at byte e * 256 + l * 4: every lane stays in its own
-// bank, no conflicts whatever the indices are); a weight pair is fetched with two 16-bit LDS reads into the halves of one
-// register, which is the operand of the same v_dot2 as the affine path.
+// bank, no conflicts whatever the indices are); a weight pair is fetched with two 16-bit LDS reads joined by one v_lshl_or,
+// and is the operand of the same v_dot2 as the affine path.
 template <int M, bool DUAL, int RU, int MAXW, bool CB>
 __global__ void __launch_bounds__(MAXW * 64)
 w4_gemv_kernel(const uint4* __restrict__ W, const uint4* __restrict__ W2, const bf16_t* __restrict__ x, int ldx,
@@ -659,7 +659,8 @@ static int w4_gemv_launch(const void* packed, const void* packed2, const void* x
     }
     // rows in flight per wave: 8 for the single-row decode kernel, fewer when a second weight or more rows share the registers
     constexpr int RU1 = (M == 1) ? 8 : 4;  // (16 / 8 rows in flight measured slower: occupancy drops to 3 waves per SIMD)
-    constexpr int RU2 = (M == 1) ? 8 : ((M <= 2) ? 4 : 2);  // M = 1: 8 rows x 2 weights per wave measured 3 % faster end to end than 4
+    // (codebook weights: the 32 raw lookups of a slice live beside the weights: 8 x 2 rows would take 168 VGPRs, 3 waves per SIMD)
+    constexpr int RU2 = (M == 1) ? (CB ? 4 : 8) : ((M <= 2) ? 4 : 2);  // M = 1: 8 rows x 2 weights per wave measured 3 % faster end to end than 4
 #define PARROT_W4_GO(DUALV, RUV, MAXWV) \
     return w4_gemv_launch_v<M, DUALV, RUV, MAXWV, CB>(packed, packed2, x, ldx, bias, residual, ldr, out, ldo, N, K, epi, na, plan, st, code)
     if (plan.nslabs <= 8) {

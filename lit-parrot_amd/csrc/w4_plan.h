@@ -93,35 +93,47 @@ __device__ __forceinline__ float w4_slice_dot(const uint4 w, const uint32_t (&xr
 // W4K: bits 4i <-> k = 8d + 2i, bits 16 + 4i <-> k = 8d + 2i + 1.
 // One instruction per address: v_and_b32_sdwa takes byte b of the (possibly >> 4) weight dword, masks the nibble and writes
 // it into byte 1 of an address register whose byte 0 permanently holds lane * 4 (dst_unused:UNUSED_PRESERVE), i.e.
-// address = nibble * 256 + lane * 4.  ds_read_u16_d16 / _d16_hi deposit the two codebook values of a pair in the halves of
-// one register.  The compiler does not track LDS reads issued from inline asm: the caller waits with w4c_wait().
-#define W4C_PAIR(P, A, SRC_LO, SEL_LO, SRC_HI, SEL_HI)                                                              \
-    asm volatile("v_and_b32_sdwa %1, 15, %2 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:" SEL_LO "\n\t" \
-                 "ds_read_u16_d16 %0, %1\n\t"                                                                       \
-                 "v_and_b32_sdwa %1, 15, %3 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:" SEL_HI "\n\t" \
-                 "ds_read_u16_d16_hi %0, %1"                                                                         \
-                 : "=&v"(P), "+v"(A)                                                                                 \
-                 : "v"(SRC_LO), "v"(SRC_HI)                                                                          \
+// address = nibble * 256 + lane * 4.  The two codebook values of a pair are read with ds_read_u16 (zero-extended) and joined
+// by one v_lshl_or_b32.  (ds_read_u16_d16_hi does NOT merge into the other half on this part: with SRAM ECC the D16 loads
+// clear the unused half - measured with tools/probes/sdwa_probe.hip - which is also why the compiler never emits them.)
+// The compiler does not track LDS reads issued from inline asm: the slice's reads are waited for in one place below.
+#define W4C_READ(R, A, SRC, SEL)                                                                                         \
+    asm volatile("v_and_b32_sdwa %1, 15, %2 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:" SEL "\n\t" \
+                 "ds_read_u16 %0, %1"                                                                                     \
+                 : "=&v"(R), "+v"(A)                                                                                      \
+                 : "v"(SRC)                                                                                               \
                  : "memory")
 __device__ __forceinline__ void w4c_slice_lookup(const uint4 w, uint32_t cb_addr, uint32_t (&pairs)[16]) {
     const uint32_t dw[4] = {w.x, w.y, w.z, w.w};
-    uint32_t a0 = cb_addr, a1 = cb_addr;  // byte 0 = lane * 4 (+ table base), byte 1 is rewritten per lookup
+    uint32_t a0 = cb_addr, a1 = cb_addr;  // byte 0 = lane * 4 (table at LDS offset 0), byte 1 is rewritten per lookup
+    uint32_t lo[16], hi[16];
 #pragma unroll
     for (int d = 0; d < 4; ++d) {
         const uint32_t lo4 = dw[d], hi4 = dw[d] >> 4;
-        W4C_PAIR(pairs[4 * d + 0], a0, lo4, "BYTE_0", lo4, "BYTE_2");
-        W4C_PAIR(pairs[4 * d + 1], a1, hi4, "BYTE_0", hi4, "BYTE_2");
-        W4C_PAIR(pairs[4 * d + 2], a0, lo4, "BYTE_1", lo4, "BYTE_3");
-        W4C_PAIR(pairs[4 * d + 3], a1, hi4, "BYTE_1", hi4, "BYTE_3");
+        W4C_READ(lo[4 * d + 0], a0, lo4, "BYTE_0");
+        W4C_READ(hi[4 * d + 0], a1, lo4, "BYTE_2");
+        W4C_READ(lo[4 * d + 1], a0, hi4, "BYTE_0");
+        W4C_READ(hi[4 * d + 1], a1, hi4, "BYTE_2");
+        W4C_READ(lo[4 * d + 2], a0, lo4, "BYTE_1");
+        W4C_READ(hi[4 * d + 2], a1, lo4, "BYTE_3");
+        W4C_READ(lo[4 * d + 3], a0, hi4, "BYTE_1");
+        W4C_READ(hi[4 * d + 3], a1, hi4, "BYTE_3");
     }
+    // (an asm statement takes at most 30 operands: the wait carries the low halves, an empty statement behind it the high ones)
     asm volatile("s_waitcnt lgkmcnt(0)"
-                 : "+v"(pairs[0]), "+v"(pairs[1]), "+v"(pairs[2]), "+v"(pairs[3]), "+v"(pairs[4]), "+v"(pairs[5]), "+v"(pairs[6]),
-                   "+v"(pairs[7]), "+v"(pairs[8]), "+v"(pairs[9]), "+v"(pairs[10]), "+v"(pairs[11]), "+v"(pairs[12]),
-                   "+v"(pairs[13]), "+v"(pairs[14]), "+v"(pairs[15])
+                 : "+v"(lo[0]), "+v"(lo[1]), "+v"(lo[2]), "+v"(lo[3]), "+v"(lo[4]), "+v"(lo[5]), "+v"(lo[6]), "+v"(lo[7]),
+                   "+v"(lo[8]), "+v"(lo[9]), "+v"(lo[10]), "+v"(lo[11]), "+v"(lo[12]), "+v"(lo[13]), "+v"(lo[14]), "+v"(lo[15])
                  :
                  : "memory");
+    asm volatile(""
+                 : "+v"(hi[0]), "+v"(hi[1]), "+v"(hi[2]), "+v"(hi[3]), "+v"(hi[4]), "+v"(hi[5]), "+v"(hi[6]), "+v"(hi[7]),
+                   "+v"(hi[8]), "+v"(hi[9]), "+v"(hi[10]), "+v"(hi[11]), "+v"(hi[12]), "+v"(hi[13]), "+v"(hi[14]), "+v"(hi[15])
+                 :
+                 : "memory");
+#pragma unroll
+    for (int j = 0; j < 16; ++j) pairs[j] = lo[j] | (hi[j] << 16);
 }
-#undef W4C_PAIR
+#undef W4C_READ
 __device__ __forceinline__ float w4c_pairs_dot(const uint32_t (&pairs)[16], const uint32_t (&xr)[16]) {
     float p0 = 0.f, p1 = 0.f;
 #pragma unroll

@@ -147,6 +147,39 @@ def w4_linear(packed: torch.Tensor, N: int, K: int, group: int, x: torch.Tensor,
     return out
 
 
+def w4c_dequant(packed: torch.Tensor, code_f32: torch.Tensor, N: int, K: int, block: int, out: torch.Tensor) -> torch.Tensor:
+    """Codebook (NF4 / FP4) W4K records -> dense bf16 (N, K) = bf16(code[q] * absmax), bitsandbytes' dequantize_4bit."""
+    if out.dtype != torch.bfloat16 or out.shape != (N, K) or out.stride(1) != 1:
+        raise ParrotHipError("w4c_dequant: out must be bf16 (N, K) with unit column stride")
+    if code_f32.dtype != torch.float32 or code_f32.numel() != 16:
+        raise ParrotHipError("w4c_dequant: the codebook is 16 fp32 values")
+    check(_hip.load().parrot_w4c_dequant(ptr(packed), ptr(code_f32), ptr(out), out.stride(0), N, K, block, stream()), "parrot_w4c_dequant")
+    return out
+
+
+def w4c_linear(packed: torch.Tensor, code_words: torch.Tensor, code_f32: torch.Tensor, N: int, K: int, block: int, x: torch.Tensor,
+               out: torch.Tensor, *, bias=None, epilogue=EPI_NONE, residual=None, packed2=None, norm: Optional[Norm] = None) -> torch.Tensor:
+    """Linear over 4-bit codebook weights.  Up to GEMV_MAX_ROWS rows: the fused dequant-into-GEMV kernel.  More rows
+    (prefill): dequantise to bf16 and multiply on the matrix cores - the order of operations of bitsandbytes' MatMul4Bit."""
+    _rows(x, "w4c_linear"), _rows(out, "w4c_linear")
+    M = x.shape[0]
+    if x.shape[1] != K or out.shape[1] != N:
+        raise ParrotHipError(f"w4c_linear: x {tuple(x.shape)} / out {tuple(out.shape)} do not match N={N} K={K}")
+    if code_words.dtype != torch.int32 or code_words.numel() != 16:
+        raise ParrotHipError("w4c_linear: the bf16 codebook is passed as 16 int32 words")
+    if M > GEMV_MAX_ROWS:
+        dense = w4c_dequant(packed, code_f32, N, K, block, torch.empty((N, K), dtype=torch.bfloat16, device=x.device))
+        dense2 = None
+        if packed2 is not None:
+            dense2 = w4c_dequant(packed2, code_f32, N, K, block, torch.empty((N, K), dtype=torch.bfloat16, device=x.device))
+        return bf16_linear(dense, x, out, bias=bias, epilogue=epilogue, residual=residual, weight2=dense2, norm=norm)
+    x, norm = _prenorm(x, norm)
+    check(_hip.load().parrot_w4c_gemv(ptr(packed), ptr(packed2), ptr(code_words), ptr(x), x.stride(0), M,
+                                      ptr(_opt_vec(bias, N, "bias")), ptr(residual), residual.stride(0) if residual is not None else 0,
+                                      ptr(out), out.stride(0), N, K, block, epilogue, _norm_arg(norm, K), stream()), "parrot_w4c_gemv")
+    return out
+
+
 def w8_quantize_rows(weight: torch.Tensor, CB: torch.Tensor, SCB: torch.Tensor) -> None:
     N, K = weight.shape
     if weight.dtype != torch.bfloat16 or not weight.is_contiguous():

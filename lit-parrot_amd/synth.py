@@ -98,8 +98,8 @@ def build_synthetic_model(config: Config, mode=None, seed: int = 1234, device="c
             del w, q
         elif isinstance(module, torch.nn.Linear):
             w = torch.randn((module.out_features, module.in_features), generator=gen, device=dev) * 0.02
-            if hasattr(module, "_quantize_weight"):  # LLM.int8: quantise on arrival, like loading a checkpoint
-                module._quantize_weight(w)
+            if hasattr(module, "_quantize_weight"):  # LLM.int8 / NF4 / FP4: quantise on arrival, like loading a checkpoint
+                module._quantize_weight(w.to(torch.bfloat16) if module.weight.dtype != torch.int8 and hasattr(module, "quant_type") else w)
             else:
                 module.weight.data.copy_(w)
             if module.bias is not None:

@@ -6,7 +6,8 @@ A context manager that replaces ``torch.nn.Linear`` while a model is being const
   * ``"gptq.int4"``     -> ``quantize.gptq.ColBlockQuantizedLinear(bits=4, tile_cols=-1)`` (utils.py:69-76)
   * ``"gptq.int4-g<N>"``-> the same with ``tile_cols=N`` (e.g. ``gptq.int4-g128``): grouped scales, which the
     reference's class supports (gptq.py:206-226) but its context manager cannot select.
-The bitsandbytes 4-bit modes of the reference (``bnb.nf4``, ``bnb.fp4``, ``-dq``) are not built.
+  * ``"bnb.nf4"``, ``"bnb.nf4-dq"``, ``"bnb.fp4"``, ``"bnb.fp4-dq"`` -> ``quantize.bnb.Linear4bit`` with the matching
+    ``quant_type`` / ``compress_statistics`` (utils.py:36-68).
 Unlike the reference (utils.py:80-83) ``torch.nn.Linear`` is restored even when the body raises.
 """
 import re
@@ -37,7 +38,15 @@ def quantized_linear_class(mode: str):
 
         return QuantizedLinear
     if mode in _BNB4:
-        raise NotImplementedError(f"{mode}: the bitsandbytes 4-bit formats are not part of this build (SURVEY §8(f)-3)")
+        from .quantize.bnb import Linear4bit
+
+        quant_type, compress = mode[4:7], mode.endswith("-dq")
+
+        class QuantizedLinear(Linear4bit):
+            def __init__(self, *args, **kwargs):
+                super().__init__(*args, quant_type=quant_type, compress_statistics=compress, **kwargs)
+
+        return QuantizedLinear
     raise ValueError(f"Unknown quantization mode: {mode}")
 
 
