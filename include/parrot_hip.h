@@ -174,6 +174,14 @@ int parrot_attn_fused_decode(const void* qkv, const void* rope_cos, const void* 
                              const int32_t* pos, int n_groups, int q_per_kv, int hs, int S, int nsplit,
                              void* workspace, void* tickets, void* k_cache, void* v_cache, void* y,
                              void* stream);
+/* The same launch with extra workgroups that read up to four byte ranges (the packed weights of the Linears that follow:
+ * out-projection, MLP) while the attention occupies only n_groups workgroups and leaves the HBM idle; nothing is written,
+ * the lines stay in L2 / the memory-side cache for the next launches.  prefetch_wgs = number of extra workgroups (0 = none). */
+int parrot_attn_fused_decode_pf(const void* qkv, const void* rope_cos, const void* rope_sin, int n_elem,
+                                const int32_t* pos, int n_groups, int q_per_kv, int hs, int S, int nsplit,
+                                void* workspace, void* tickets, void* k_cache, void* v_cache, void* y,
+                                const void* const* prefetch_ptrs, const int64_t* prefetch_bytes, int n_prefetch,
+                                int prefetch_wgs, void* stream);
 
 /* ---- small ops of the step ----------------------------------------------------------
  * x[m] = wte[tokens[(pos ? *pos : 0) + m]]   (lit_gpt/model.py:99)                    */

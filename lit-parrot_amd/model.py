@@ -36,6 +36,18 @@ from .rmsnorm import RMSNorm
 
 # parallel-residual blocks: overlap the MLP up-projection with the attention branch (M = 1); PARROT_PARALLEL_BRANCHES=0 disables
 PARALLEL_BRANCHES = os.environ.get("PARROT_PARALLEL_BRANCHES", "1") != "0"
+# Decode attention leaves the HBM idle (32 busy workgroups, ~3 MB of K/V): extra workgroups of the same launch read the
+# weights of the Linears that follow.  0 = off, 1 = out-projection, 2 = + MLP up-projection(s), 3 = + MLP down-projection.
+ATTN_PREFETCH = int(os.environ.get("PARROT_ATTN_PREFETCH", "0"))
+ATTN_PREFETCH_WGS = int(os.environ.get("PARROT_ATTN_PREFETCH_WGS", "224"))
+
+
+def _streamed_weight(mod: nn.Module) -> Optional[torch.Tensor]:
+    """The device buffer a Linear's decode kernel streams (kernel-native packed weights for the 4-bit classes)."""
+    if hasattr(mod, "packed"):
+        return mod.packed()
+    w = getattr(mod, "weight", None)
+    return w.data if w is not None and w.is_cuda else None
 
 # decode step of sequential-residual models: pull the NEXT Linear's weights on chip from a side stream while the current
 # kernel runs (PARROT_PREFETCH=0 disables; =N limits each prefetch to N MiB)
@@ -352,7 +364,8 @@ class Block(nn.Module):
                     "No checkpoint amongst the ones we support uses this configuration"
                     " (non-parallel residual and shared attention norm)."
                 )
-            self.attn.run_rows(ws, ws.x, pos, S, k_cache, v_cache, rope, nsplit, rope_local, norm=self.norm_1)  # -> ws.y
+            self.attn.run_rows(ws, ws.x, pos, S, k_cache, v_cache, rope, nsplit, rope_local, norm=self.norm_1,
+                               upcoming=self.mlp.streamed_modules(ATTN_PREFETCH))  # -> ws.y
             _linear(self.attn.proj, ws.y, ws.x, epilogue=EPI_RESIDUAL, residual=ws.x)  # x = x + h
             self.mlp.run_rows(ws, ws.x, residual=ws.x, out=ws.x, norm=self.norm_2)  # x = x + mlp(norm_2(x))
 
@@ -391,15 +404,20 @@ class CausalSelfAttention(nn.Module):
 
     def run_rows(self, ws: Workspace, x: torch.Tensor, pos: torch.Tensor, S: int, k_cache: torch.Tensor,
                  v_cache: torch.Tensor, rope: RoPECache, nsplit: int, rope_local: bool = False,
-                 norm: Optional[nn.Module] = None) -> torch.Tensor:
+                 norm: Optional[nn.Module] = None, upcoming: Tuple[nn.Module, ...] = ()) -> torch.Tensor:
         """(norm +) qkv linear, split + RoPE + cache append, attention over the cache; leaves the heads in ``ws.y``
         (the output projection is fused with the residual add by the caller).  A single new token takes the fused
         kernel (one launch); several rows (prefill) take rope_kvappend + attn_decode over all rows."""
         c = self.config
         _linear(self.attn, x, ws.qkv, norm=norm)
         if ws.M == 1 and not rope_local and c.q_per_kv <= ops.FUSED_ATTN_MAX_Q_PER_KV:
+            prefetch = None
+            if ATTN_PREFETCH > 0:
+                mods = (self.proj,) + tuple(upcoming)
+                prefetch = [t for t in (_streamed_weight(m) for m in mods) if t is not None][:4]
             return ops.attn_fused_decode(ws.qkv, rope[0], rope[1], c.rope_n_elem, pos, k_cache, v_cache, c.n_query_groups,
-                                         c.q_per_kv, c.head_size, S, nsplit, ws.attn_ws(c, nsplit), ws.tickets, ws.y)
+                                         c.q_per_kv, c.head_size, S, nsplit, ws.attn_ws(c, nsplit), ws.tickets, ws.y,
+                                         prefetch=prefetch, prefetch_wgs=ATTN_PREFETCH_WGS)
         ops.rope_kvappend(ws.qkv, rope[0], rope[1], c.rope_n_elem, pos, c.n_query_groups, c.q_per_kv, c.head_size, S,
                           ws.q, k_cache, v_cache, rope_local)
         return ops.attn_decode(ws.q, pos, k_cache, v_cache, c.n_query_groups, c.q_per_kv, c.head_size, S, nsplit,
@@ -438,6 +456,9 @@ class GptNeoxMLP(nn.Module):
         self.run_up(ws, x, norm=norm)
         return self.run_down(ws, residual=residual, out=out)
 
+    def streamed_modules(self, level: int) -> Tuple[nn.Module, ...]:
+        return ((self.fc,) if level >= 2 else ()) + ((self.proj,) if level >= 3 else ())
+
     def run_up(self, ws, x: torch.Tensor, *, norm: Optional[nn.Module] = None) -> torch.Tensor:
         return _linear(self.fc, x, ws.h, epilogue=EPI_GELU, norm=norm)  # exact-erf GELU fused (model.py:284-287)
 
@@ -461,6 +482,9 @@ class LLaMAMLP(nn.Module):
                  norm: Optional[nn.Module] = None) -> torch.Tensor:
         self.run_up(ws, x, norm=norm)
         return self.run_down(ws, residual=residual, out=out)
+
+    def streamed_modules(self, level: int) -> Tuple[nn.Module, ...]:
+        return ((self.fc_1, self.fc_2) if level >= 2 else ()) + ((self.proj,) if level >= 3 else ())
 
     def run_up(self, ws, x: torch.Tensor, *, norm: Optional[nn.Module] = None) -> torch.Tensor:
         return _linear(self.fc_1, x, ws.h, epilogue=EPI_SWIGLU, partner=self.fc_2, norm=norm)  # silu(fc_1 x) * fc_2 x (model.py:297-301)
