@@ -616,8 +616,9 @@ int parrot_attn_fused_decode_pf(const void* qkv, const void* rope_cos, const voi
         pf.ptr[r] = qkv;  // (a valid address for the empty ranges)
         pf.bytes[r] = 0;
         if (r < n_prefetch && prefetch_wgs > 0) {
-            PARROT_REQUIRE(prefetch_ptrs && prefetch_bytes && prefetch_ptrs[r] && prefetch_bytes[r] >= 0 && aligned16(prefetch_ptrs[r]),
-                           "attn_fused_decode: prefetch ranges must be 16-byte aligned device buffers");
+            PARROT_REQUIRE(prefetch_ptrs && prefetch_bytes && prefetch_bytes[r] >= 0, "attn_fused_decode: bad prefetch range");
+            if (prefetch_bytes[r] < 16) continue;  // empty range
+            PARROT_REQUIRE(prefetch_ptrs[r] && aligned16(prefetch_ptrs[r]), "attn_fused_decode: prefetch ranges must be 16-byte aligned device buffers");
             pf.ptr[r] = prefetch_ptrs[r];
             pf.bytes[r] = prefetch_bytes[r] & ~(int64_t)15;
         }

@@ -355,6 +355,15 @@ static int gemm_launch(int kid, const void* Wp, const void* W2p, const void* x, 
                   (const float*)part2, ksplit, M, N, (const bf16_t*)bias, (const bf16_t*)residual, ldr, (bf16_t*)out, ldo, epilogue);
 }
 
+// second-generation bf16 kernel (gemm2.hip)
+int gemm2_ksplit(int M, int N, int K);
+bool gemm2_enabled();
+int gemm2_launch(const void* W, const void* x, int ldx, int M, const void* bias, const void* residual, int ldr, void* out, int ldo,
+                 int N, int K, int epilogue, float* part, hipStream_t st, int* ksplit_out);
+static bool gemm2_takes(int K, int ldx, int epilogue, const void* W, const void* x) {
+    return gemm2_enabled() && epilogue != PARROT_EPI_SWIGLU && K % 64 == 0 && ldx % 8 == 0 && aligned16(W) && aligned16(x);
+}
+
 }  // namespace parrot
 
 using namespace parrot;
@@ -371,7 +380,11 @@ int64_t parrot_gemm_workspace_floats(int M, int N, int K, int group, int epilogu
         gs_tiles = group / GBK > 0 ? group / GBK : 1;
     }
     if (K % GBK == 0) {
-        const int ks = gemm_ksplit(M, N, K, gs_tiles);
+        int ks = gemm_ksplit(M, N, K, gs_tiles);
+        if (group == 0 && K % 64 == 0 && epilogue != PARROT_EPI_SWIGLU && gemm2_enabled()) {  // whichever bf16 kernel ends up running
+            const int ks2 = gemm2_ksplit(M, N, K);
+            if (ks2 > ks) ks = ks2;
+        }
         if (ks > 1) n += (int64_t)ks * M * N * (epilogue == PARROT_EPI_SWIGLU ? 2 : 1);
     }
     return n;
@@ -387,6 +400,15 @@ int parrot_bf16_gemm(const void* W, const void* W2, const void* x, int ldx, int 
     PARROT_UNSUPPORTED(K % GBK == 0, "bf16_gemm: K=%d must be a multiple of %d", K, GBK);
     PARROT_UNSUPPORTED(!(epilogue == PARROT_EPI_SWIGLU && bias), "bf16_gemm: SWIGLU epilogue takes no bias");
     PARROT_REQUIRE(M <= 65535 * 64, "bf16_gemm: M too large");
+    if (gemm2_takes(K, ldx, epilogue, W, x)) {
+        int ks = 1;
+        rc = gemm2_launch(W, x, ldx, M, bias, residual, ldr, out, ldo, N, K, epilogue, (float*)workspace, (hipStream_t)stream, &ks);
+        if (rc != PARROT_OK || ks == 1) return rc;
+        const int64_t n = (int64_t)M * N;
+        return launch(K_BF16_GEMM, gemm_splitk_epilogue_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                      (const float*)workspace, (const float*)nullptr, ks, M, N, (const bf16_t*)bias, (const bf16_t*)residual, ldr,
+                      (bf16_t*)out, ldo, epilogue);
+    }
     W4Plan plan = {};
     return gemm_launch<false>(K_BF16_GEMM, W, W2, x, ldx, M, bias, residual, ldr, out, ldo, N, K, epilogue, nullptr, (float*)workspace,
                               plan, 1, (hipStream_t)stream);

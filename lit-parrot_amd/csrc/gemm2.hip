@@ -1,0 +1,155 @@
+// Prefill Linear on bf16 weights, second generation: 128 x 128 x 64 tiles staged global -> LDS by LDS-DMA.
+//
+// Reference: torch.nn.Linear on bf16 over the T prompt rows (lit_gpt/model.py:29,188,190,281-295).
+// out[M, N] = epilogue(x[M, K] @ W[N, K]^T + b): both operands K-contiguous, so a K-tile of either is 128 rows x 128 B.
+//
+// Why a second kernel (gemm.hip stays for int4 and SwiGLU): the first one stages through registers + ds_write in 32-deep
+// K-tiles; with 64 x 64 tiles each wave issues 2 MFMAs per barrier and the loop is bound by LDS traffic and barriers
+// (measured 13 % of the bf16 matrix peak, no better with more workgroups per CU or split-K: tools/ab_gemm_tiles.sh).
+// Here:  * global_load_lds_dwordx4: one wave instruction moves 8 rows x 128 B straight into LDS (no VGPRs, no ds_write pass);
+//          the tile of step t+1 is in flight while step t is multiplied, ONE barrier per 64-deep K-step;
+//        * the LDS image is lane-linear per instruction (hardware), so the bank-conflict swizzle is applied on the SOURCE
+//          side: 16-byte slot s of row r is stored at slot s ^ ((r >> 1) & 7) - rows are 128 B, two per 256-B bank row, and the
+//          16 rows a ds_read_b128 lane group touches land on 16 different 16-byte slots;
+//        * 4 waves as 2 x 2, each 64 x 64 = 2 x 2 tiles of v_mfma_f32_32x32x16_bf16, 16 MFMAs per wave and barrier.
+// Short launches (few 128 x 128 tiles) split K; the second stage (gemm.hip's fixed-order sum + epilogue) is shared.
+#include <stdlib.h>
+
+#include "parrot_common.h"
+
+namespace parrot {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef __attribute__((ext_vector_type(16))) float f32x16_t;
+
+constexpr int G2M = 128, G2N = 128, G2K = 64;
+constexpr int G2_TILE16 = 128 * 8;  // 16-byte units of one operand tile (128 rows x 128 B)
+
+template <bool SPLIT>
+__global__ void __launch_bounds__(256)
+gemm2_kernel(const bf16_t* __restrict__ A, int lda, int M, const bf16_t* __restrict__ W, int N, int K,
+             const bf16_t* __restrict__ bias, const bf16_t* residual, int ldr, bf16_t* out, int ldo, int epi, int ksplit,
+             float* __restrict__ part) {
+    // ONE LDS object (a second one beside an LDS-DMA target can cost a vmcnt(0) in front of every fragment read)
+    __shared__ __attribute__((aligned(1024))) uint4 smem[2][2][G2_TILE16];  // [buffer][A | B][row * 8 + slot]
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int m0 = blockIdx.y * G2M, n0 = blockIdx.x * G2N;
+    const int lr = lane & 31, lh = lane >> 5;
+    const int ktiles = K / G2K;
+    const int kt_per = SPLIT ? ktiles / ksplit : ktiles;
+    const int kt_begin = SPLIT ? (int)blockIdx.z * kt_per : 0, kt_end = kt_begin + kt_per;
+
+    // LDS-DMA assignment: a tile is 16 wave-instructions of 8 rows; wave w issues instructions 4w .. 4w+3 of A and of B.
+    // Lane l of an instruction: row r = r0 + l / 8, LDS slot l % 8 <- global slot (l % 8) ^ ((r >> 1) & 7).
+    const int l_row = lane >> 3, l_slot = lane & 7;
+    const bf16_t* a_src[4];
+    const bf16_t* b_src[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int r = (wave * 4 + i) * 8 + l_row;
+        const int gs = l_slot ^ ((r >> 1) & 7);
+        a_src[i] = A + (int64_t)min(m0 + r, M - 1) * lda + gs * 8;
+        b_src[i] = W + (int64_t)min(n0 + r, N - 1) * K + gs * 8;
+    }
+    auto issue = [&](int kt, int buf) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int r0 = (wave * 4 + i) * 8;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a_src[i] + (int64_t)kt * G2K),
+                                             (__attribute__((address_space(3))) void*)&smem[buf][0][r0 * 8], 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(b_src[i] + (int64_t)kt * G2K),
+                                             (__attribute__((address_space(3))) void*)&smem[buf][1][r0 * 8], 16, 0, 0);
+        }
+    };
+
+    f32x16_t acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // fragment rows of this lane and their swizzle keys (constant over the K loop)
+    int a_row[2], b_row[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        a_row[i] = wm * 64 + i * 32 + lr;
+        b_row[i] = wn * 64 + i * 32 + lr;
+    }
+
+    issue(kt_begin, 0);
+    for (int kt = kt_begin; kt < kt_end; ++kt) {
+        const int buf = (kt - kt_begin) & 1;
+        __syncthreads();  // (waits vmcnt(0) first) tile kt has landed for every wave; everybody is done reading buffer buf ^ 1
+        if (kt + 1 < kt_end) issue(kt + 1, buf ^ 1);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+            const int slot = ks * 2 + lh;
+            bf16x8_t af[2], bfr[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                af[i] = __builtin_bit_cast(bf16x8_t, smem[buf][0][a_row[i] * 8 + (slot ^ ((a_row[i] >> 1) & 7))]);
+                bfr[i] = __builtin_bit_cast(bf16x8_t, smem[buf][1][b_row[i] * 8 + (slot ^ ((b_row[i] >> 1) & 7))]);
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+        }
+    }
+
+    // C layout of the 32x32 MFMA: column = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int col = n0 + wn * 64 + j * 32 + lr;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                if (row < M && col < N) {
+                    if constexpr (SPLIT)
+                        part[((int64_t)blockIdx.z * M + row) * N + col] = acc[i][j][r];
+                    else
+                        out[(int64_t)row * ldo + col] = apply_epilogue(epi, acc[i][j][r], 0.f, bias, residual ? residual + (int64_t)row * ldr : nullptr, col);
+                }
+            }
+        }
+}
+
+// K splits when the 128 x 128 tiles alone leave most of the chip idle: aim at ~256 - 512 workgroups, whole 64-deep steps,
+// at least 8 per split
+int gemm2_ksplit(int M, int N, int K) {
+    const int64_t tiles = (int64_t)((M + G2M - 1) / G2M) * ((N + G2N - 1) / G2N);
+    const int ktiles = K / G2K;
+    int ks = tiles >= 192 ? 1 : (int)(384 / (tiles > 0 ? tiles : 1));
+    if (ks > 8) ks = 8;
+    while (ks > 1 && (ktiles % ks != 0 || ktiles / ks < 8)) --ks;
+    return ks < 1 ? 1 : ks;
+}
+
+bool gemm2_enabled() {
+    static int env = -1;  // PARROT_GEMM2=0: A/B against the first-generation kernel
+    if (env < 0) {
+        const char* e = getenv("PARROT_GEMM2");
+        env = e ? atoi(e) : 1;
+    }
+    return env != 0;
+}
+
+int gemm2_launch(const void* W, const void* x, int ldx, int M, const void* bias, const void* residual, int ldr, void* out, int ldo,
+                 int N, int K, int epilogue, float* part, hipStream_t st, int* ksplit_out) {
+    const int ks = gemm2_ksplit(M, N, K);
+    *ksplit_out = ks;
+    PARROT_REQUIRE(ks == 1 || part != nullptr, "bf16_gemm: this shape splits K %d ways and needs the workspace of parrot_gemm_workspace_floats", ks);
+    const dim3 grid((N + G2N - 1) / G2N, (M + G2M - 1) / G2M, ks);
+    if (ks > 1)
+        return launch(K_BF16_GEMM, gemm2_kernel<true>, grid, dim3(256), 0, st, (const bf16_t*)x, ldx, M, (const bf16_t*)W, N, K,
+                      (const bf16_t*)bias, (const bf16_t*)residual, ldr, (bf16_t*)out, ldo, epilogue, ks, part);
+    return launch(K_BF16_GEMM, gemm2_kernel<false>, grid, dim3(256), 0, st, (const bf16_t*)x, ldx, M, (const bf16_t*)W, N, K,
+                  (const bf16_t*)bias, (const bf16_t*)residual, ldr, (bf16_t*)out, ldo, epilogue, ks, part);
+}
+
+}  // namespace parrot

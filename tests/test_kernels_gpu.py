@@ -246,6 +246,25 @@ def test_bf16_gemm_matches_oracle(N, K, M):
     assert_bf16_close(a, b.float(), ulps=1, atol=2e-3, what="norm + gemm vs fused gemv")
 
 
+@pytest.mark.parametrize("M,N,K,epi", [(512, 1024, 4096, EPI_NONE), (300, 389, 1024, EPI_RESIDUAL), (129, 3200, 512, EPI_GELU),
+                                       (1000, 256, 2048, EPI_NONE), (40, 128, 64, EPI_RESIDUAL)])
+def test_bf16_gemm_lds_dma_kernel_tiles_splits_and_ragged_edges(M, N, K, epi):
+    """The 128 x 128 x 64 LDS-DMA kernel (gemm2.hip): K split (few tiles), no split (many tiles), rows / columns that do not
+    fill the last tile, a single K-step; every epilogue it takes."""
+    g = gen(36)
+    W = (torch.randn(N, K, generator=g) * 0.02).to(BF)
+    x = torch.randn(M, K, generator=g).to(BF)
+    bias = (torch.randn(N, generator=g) * 0.1).to(BF)
+    res = torch.randn(M, N, generator=g).to(BF)
+    out = torch.full((M + 1, N), 7.0, dtype=BF, device=DEV)  # one guard row behind the result
+    ops.bf16_linear(W.to(DEV), x.to(DEV), out[:M], bias=bias.to(DEV), epilogue=epi, residual=res.to(DEV) if epi == EPI_RESIDUAL else None)
+    want = expected_epilogue(x.double() @ W.double().t(), None, bias, res, epi)
+    # residual: the Linear's result is rounded to bf16 BEFORE the add (a reference rounding point); where the sum cancels, one
+    # ulp of that intermediate (2^-8 of |acc| <~ 2) is many ulps of the small result
+    assert_bf16_close(out[:M], want, ulps=1, atol=8e-3 if epi == EPI_RESIDUAL else 2e-3, what=f"bf16 gemm2 {M}x{N}x{K} epi {epi}")
+    assert torch.all(out[M] == 7.0), "wrote past the last row"
+
+
 # ------------------------------------------------------------------------------------------------ dense bf16
 @pytest.mark.parametrize("N,K", [(64, 128), (100, 768), (64, 4096), (32, 16384), (16, 3072), (8, 32768), (40, 352)])
 @pytest.mark.parametrize("M", [1, 2, 3])
