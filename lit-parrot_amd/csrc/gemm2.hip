@@ -7,7 +7,8 @@
 // K-tiles; with 64 x 64 tiles each wave issues 2 MFMAs per barrier and the loop is bound by LDS traffic and barriers
 // (measured 13 % of the bf16 matrix peak, no better with more workgroups per CU or split-K: tools/ab_gemm_tiles.sh).
 // Here:  * global_load_lds_dwordx4: one wave instruction moves 8 rows x 128 B straight into LDS (no VGPRs, no ds_write pass);
-//          the tile of step t+1 is in flight while step t is multiplied, ONE barrier per 64-deep K-step;
+//          a ring of three LDS buffers keeps the tiles of steps t+1 and t+2 in flight while step t is multiplied (counted
+//          vmcnt + raw s_barrier), ONE barrier per 64-deep K-step;
 //        * the LDS image is lane-linear per instruction (hardware), so the bank-conflict swizzle is applied on the SOURCE
 //          side: 16-byte slot s of row r is stored at slot s ^ ((r >> 1) & 7) - rows are 128 B, two per 256-B bank row, and the
 //          16 rows a ds_read_b128 lane group touches land on 16 different 16-byte slots;
@@ -23,22 +24,55 @@ typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
 typedef __attribute__((ext_vector_type(16))) float f32x16_t;
 
 constexpr int G2M = 128, G2N = 128, G2K = 64;
+#ifndef PARROT_G2_PRIO
+#define PARROT_G2_PRIO 0
+#endif
+constexpr bool G2_PRIO = PARROT_G2_PRIO;  // raise the wave priority over the MFMA cluster (build-time A/B)
 constexpr int G2_TILE16 = 128 * 8;  // 16-byte units of one operand tile (128 rows x 128 B)
 
-template <bool SPLIT>
+// Workgroup id -> (m tile, n tile, K split).  Workgroups are dealt to the 8 XCDs round-robin and each XCD has its own L2, so
+// the tiles that share operands must (a) sit on one XCD and (b) run at the same time: XCD x owns a contiguous range of
+// n tiles; its workgroups walk super-blocks of GM m-tiles x GN n-tiles (GM * GN = what is resident on an XCD at once), m
+// fastest.  Without this every 128-row band of W is fetched from HBM once per m tile (measured: 26 % of the MFMA peak at
+// M = 2048 with the plain x-fastest grid).
+struct G2Map {
+    int MT, NT, GM, GN, xcd_ok;
+};
+__device__ __forceinline__ void g2_tile_of(const G2Map& mp, int id, int& mt, int& nt, int& z) {
+    const int per_z = mp.MT * mp.NT;
+    z = id / per_z;
+    int t = id - z * per_z;
+    if (!mp.xcd_ok) {
+        mt = t % mp.MT;
+        nt = t / mp.MT;
+        return;
+    }
+    const int x = t & 7, j = t >> 3, NTx = mp.NT >> 3;
+    const int B = mp.GM * mp.GN;
+    const int sb = j / B, r = j - sb * B;
+    const int mblocks = mp.MT / mp.GM;
+    const int mb = sb % mblocks, nb = sb / mblocks;
+    mt = mb * mp.GM + r % mp.GM;
+    nt = x * NTx + nb * mp.GN + r / mp.GM;
+}
+
+// G2_NBUF = LDS ring depth: 2 (64 KB, two workgroups per CU) or 3 (96 KB, one workgroup per CU, two tiles in flight)
+template <bool SPLIT, int G2_NBUF>
 __global__ void __launch_bounds__(256)
 gemm2_kernel(const bf16_t* __restrict__ A, int lda, int M, const bf16_t* __restrict__ W, int N, int K,
              const bf16_t* __restrict__ bias, const bf16_t* residual, int ldr, bf16_t* out, int ldo, int epi, int ksplit,
-             float* __restrict__ part) {
+             float* __restrict__ part, G2Map mp) {
     // ONE LDS object (a second one beside an LDS-DMA target can cost a vmcnt(0) in front of every fragment read)
-    __shared__ __attribute__((aligned(1024))) uint4 smem[2][2][G2_TILE16];  // [buffer][A | B][row * 8 + slot]
+    __shared__ __attribute__((aligned(1024))) uint4 smem[G2_NBUF][2][G2_TILE16];  // [buffer][A | B][row * 8 + slot]
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
-    const int m0 = blockIdx.y * G2M, n0 = blockIdx.x * G2N;
+    int mt_, nt_, z_;
+    g2_tile_of(mp, blockIdx.x, mt_, nt_, z_);
+    const int m0 = mt_ * G2M, n0 = nt_ * G2N, zsplit = z_;
     const int lr = lane & 31, lh = lane >> 5;
     const int ktiles = K / G2K;
     const int kt_per = SPLIT ? ktiles / ksplit : ktiles;
-    const int kt_begin = SPLIT ? (int)blockIdx.z * kt_per : 0, kt_end = kt_begin + kt_per;
+    const int kt_begin = SPLIT ? zsplit * kt_per : 0, kt_end = kt_begin + kt_per;
 
     // LDS-DMA assignment: a tile is 16 wave-instructions of 8 rows; wave w issues instructions 4w .. 4w+3 of A and of B.
     // Lane l of an instruction: row r = r0 + l / 8, LDS slot l % 8 <- global slot (l % 8) ^ ((r >> 1) & 7).
@@ -79,11 +113,21 @@ gemm2_kernel(const bf16_t* __restrict__ A, int lda, int M, const bf16_t* __restr
         b_row[i] = wn * 64 + i * 32 + lr;
     }
 
+    // Ring of G2_NBUF buffers.  An LDS-DMA load counts on vmcnt and retires in order (8 per wave and tile): before the
+    // barrier of step t every wave waits until at most the 8 loads of tile t+1 are outstanding, i.e. ITS pieces of tile t have
+    // landed; past the barrier everybody's have, and everybody is done reading the buffer of step t-1, which the loads of
+    // tile t+2 issued right behind the barrier overwrite.  A raw s_barrier: __syncthreads() would drain vmcnt(0).
     issue(kt_begin, 0);
+    if (G2_NBUF > 2 && kt_begin + 1 < kt_end) issue(kt_begin + 1, 1);
+    int buf = 0;
     for (int kt = kt_begin; kt < kt_end; ++kt) {
-        const int buf = (kt - kt_begin) & 1;
-        __syncthreads();  // (waits vmcnt(0) first) tile kt has landed for every wave; everybody is done reading buffer buf ^ 1
-        if (kt + 1 < kt_end) issue(kt + 1, buf ^ 1);
+        if (G2_NBUF > 2 && kt + 1 < kt_end)
+            asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (kt + G2_NBUF - 1 < kt_end) issue(kt + G2_NBUF - 1, buf >= 1 ? buf - 1 : G2_NBUF - 1);  // (buf + NBUF - 1) % NBUF
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
             const int slot = ks * 2 + lh;
@@ -93,11 +137,14 @@ gemm2_kernel(const bf16_t* __restrict__ A, int lda, int M, const bf16_t* __restr
                 af[i] = __builtin_bit_cast(bf16x8_t, smem[buf][0][a_row[i] * 8 + (slot ^ ((a_row[i] >> 1) & 7))]);
                 bfr[i] = __builtin_bit_cast(bf16x8_t, smem[buf][1][b_row[i] * 8 + (slot ^ ((b_row[i] >> 1) & 7))]);
             }
+            if (G2_PRIO) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
                 for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+            if (G2_PRIO) __builtin_amdgcn_s_setprio(0);
         }
+        buf = buf + 1 == G2_NBUF ? 0 : buf + 1;
     }
 
     // C layout of the 32x32 MFMA: column = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
@@ -111,7 +158,7 @@ gemm2_kernel(const bf16_t* __restrict__ A, int lda, int M, const bf16_t* __restr
                 const int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
                 if (row < M && col < N) {
                     if constexpr (SPLIT)
-                        part[((int64_t)blockIdx.z * M + row) * N + col] = acc[i][j][r];
+                        part[((int64_t)zsplit * M + row) * N + col] = acc[i][j][r];
                     else
                         out[(int64_t)row * ldo + col] = apply_epilogue(epi, acc[i][j][r], 0.f, bias, residual ? residual + (int64_t)row * ldr : nullptr, col);
                 }
@@ -124,7 +171,12 @@ gemm2_kernel(const bf16_t* __restrict__ A, int lda, int M, const bf16_t* __restr
 int gemm2_ksplit(int M, int N, int K) {
     const int64_t tiles = (int64_t)((M + G2M - 1) / G2M) * ((N + G2N - 1) / G2N);
     const int ktiles = K / G2K;
-    int ks = tiles >= 192 ? 1 : (int)(384 / (tiles > 0 ? tiles : 1));
+    static int target = -1;  // PARROT_GEMM2_SPLIT_TARGET: workgroups to aim at when splitting (two fit on a CU: 512 fill the chip)
+    if (target < 0) {
+        const char* e = getenv("PARROT_GEMM2_SPLIT_TARGET");
+        target = e ? atoi(e) : 512;
+    }
+    int ks = tiles >= 192 ? 1 : (int)(target / (tiles > 0 ? tiles : 1));
     if (ks > 8) ks = 8;
     while (ks > 1 && (ktiles % ks != 0 || ktiles / ks < 8)) --ks;
     return ks < 1 ? 1 : ks;
@@ -139,17 +191,44 @@ bool gemm2_enabled() {
     return env != 0;
 }
 
+static int g2_largest_divisor_le(int n, int cap) {
+    for (int d = cap < n ? cap : n; d > 1; --d)
+        if (n % d == 0) return d;
+    return 1;
+}
+
 int gemm2_launch(const void* W, const void* x, int ldx, int M, const void* bias, const void* residual, int ldr, void* out, int ldo,
                  int N, int K, int epilogue, float* part, hipStream_t st, int* ksplit_out) {
+    static int nbuf_env = -1;  // PARROT_GEMM2_NBUF = 2 | 3 (A/B)
+    if (nbuf_env < 0) {
+        const char* e = getenv("PARROT_GEMM2_NBUF");
+        nbuf_env = e ? atoi(e) : 0;
+    }
     const int ks = gemm2_ksplit(M, N, K);
     *ksplit_out = ks;
     PARROT_REQUIRE(ks == 1 || part != nullptr, "bf16_gemm: this shape splits K %d ways and needs the workspace of parrot_gemm_workspace_floats", ks);
-    const dim3 grid((N + G2N - 1) / G2N, (M + G2M - 1) / G2M, ks);
-    if (ks > 1)
-        return launch(K_BF16_GEMM, gemm2_kernel<true>, grid, dim3(256), 0, st, (const bf16_t*)x, ldx, M, (const bf16_t*)W, N, K,
-                      (const bf16_t*)bias, (const bf16_t*)residual, ldr, (bf16_t*)out, ldo, epilogue, ks, part);
-    return launch(K_BF16_GEMM, gemm2_kernel<false>, grid, dim3(256), 0, st, (const bf16_t*)x, ldx, M, (const bf16_t*)W, N, K,
-                  (const bf16_t*)bias, (const bf16_t*)residual, ldr, (bf16_t*)out, ldo, epilogue, ks, part);
+    G2Map mp;
+    mp.MT = (M + G2M - 1) / G2M;
+    mp.NT = (N + G2N - 1) / G2N;
+    const int64_t total = (int64_t)mp.MT * mp.NT * ks;
+    PARROT_UNSUPPORTED(total < (1ll << 31), "bf16_gemm: too many tiles");
+    // measured (tools/ab_gemm2.sh, StableLM-3B): 2 x 2-deep beats the 3-deep ring at one workgroup per CU at 512 and at 2048 rows
+    const int nbuf = nbuf_env == 3 ? 3 : 2;
+    const int resident_per_xcd = nbuf == 3 ? 32 : 64;
+    mp.xcd_ok = (mp.NT % 8 == 0);
+    mp.GM = g2_largest_divisor_le(mp.MT, 8);
+    mp.GN = mp.xcd_ok ? g2_largest_divisor_le(mp.NT / 8, resident_per_xcd / mp.GM > 0 ? resident_per_xcd / mp.GM : 1) : 1;
+    const dim3 grid((unsigned)total);
+#define PARROT_G2_GO(SPLITV, NBUFV)                                                                                          \
+    return launch(K_BF16_GEMM, gemm2_kernel<SPLITV, NBUFV>, grid, dim3(256), 0, st, (const bf16_t*)x, ldx, M, (const bf16_t*)W, N, K, \
+                  (const bf16_t*)bias, (const bf16_t*)residual, ldr, (bf16_t*)out, ldo, epilogue, ks, part, mp)
+    if (ks > 1) {
+        if (nbuf == 3) PARROT_G2_GO(true, 3);
+        PARROT_G2_GO(true, 2);
+    }
+    if (nbuf == 3) PARROT_G2_GO(false, 3);
+    PARROT_G2_GO(false, 2);
+#undef PARROT_G2_GO
 }
 
 }  // namespace parrot
