@@ -351,7 +351,7 @@ static int gemm_launch(int kid, const void* Wp, const void* W2p, const void* x, 
 #undef PARROT_GEMM_GO2
     if (rc != PARROT_OK || ksplit == 1) return rc;
     const int64_t n = (int64_t)M * N;
-    return launch(kid, gemm_splitk_epilogue_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (const float*)part,
+    return launch(K_GEMM_SPLITK, gemm_splitk_epilogue_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (const float*)part,
                   (const float*)part2, ksplit, M, N, (const bf16_t*)bias, (const bf16_t*)residual, ldr, (bf16_t*)out, ldo, epilogue);
 }
 
@@ -360,6 +360,12 @@ int gemm2_ksplit(int M, int N, int K);
 bool gemm2_enabled();
 int gemm2_launch(const void* W, const void* x, int ldx, int M, const void* bias, const void* residual, int ldr, void* out, int ldo,
                  int N, int K, int epilogue, float* part, hipStream_t st, int* ksplit_out);
+bool gemm2_w4_takes(const W4Plan& plan, int K);
+int gemm2_w4_ksplit(int M, int N, int K, const W4Plan& plan);
+int64_t gemm2_w4_xs_floats(int M, const W4Plan& plan);
+int gemm2_w4_launch(const void* Wq, const void* Wq2, const void* x, int ldx, int M, const void* bias, const void* residual, int ldr,
+                    void* out, int ldo, int N, int K, int epilogue, float* workspace, const W4Plan& plan, hipStream_t st, int* ksplit_out,
+                    float** part_out, float** part2_out);
 static bool gemm2_takes(int K, int ldx, int epilogue, const void* W, const void* x) {
     return gemm2_enabled() && epilogue != PARROT_EPI_SWIGLU && K % 64 == 0 && ldx % 8 == 0 && aligned16(W) && aligned16(x);
 }
@@ -387,6 +393,14 @@ int64_t parrot_gemm_workspace_floats(int M, int N, int K, int group, int epilogu
         }
         if (ks > 1) n += (int64_t)ks * M * N * (epilogue == PARROT_EPI_SWIGLU ? 2 : 1);
     }
+    if (group != 0 && K % 32 == 0) {  // the second-generation int4 kernel lays the workspace out differently: cover both
+        W4Plan plan;
+        if (w4_make_plan(N, K, group, &plan) == PARROT_OK && gemm2_w4_takes(plan, K)) {
+            const int ks2 = gemm2_w4_ksplit(M, N, K, plan);
+            const int64_t n2 = gemm2_w4_xs_floats(M, plan) + (ks2 > 1 ? (int64_t)ks2 * M * N * (epilogue == PARROT_EPI_SWIGLU ? 2 : 1) : 0);
+            if (n2 > n) n = n2;
+        }
+    }
     return n;
 }
 
@@ -405,7 +419,7 @@ int parrot_bf16_gemm(const void* W, const void* W2, const void* x, int ldx, int 
         rc = gemm2_launch(W, x, ldx, M, bias, residual, ldr, out, ldo, N, K, epilogue, (float*)workspace, (hipStream_t)stream, &ks);
         if (rc != PARROT_OK || ks == 1) return rc;
         const int64_t n = (int64_t)M * N;
-        return launch(K_BF16_GEMM, gemm_splitk_epilogue_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+        return launch(K_GEMM_SPLITK, gemm_splitk_epilogue_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
                       (const float*)workspace, (const float*)nullptr, ks, M, N, (const bf16_t*)bias, (const bf16_t*)residual, ldr,
                       (bf16_t*)out, ldo, epilogue);
     }
@@ -428,9 +442,19 @@ int parrot_w4_gemm(const void* packed, const void* packed2, const void* x, int l
     rc = w4_make_plan(N, K, group, &plan);
     if (rc != PARROT_OK) return rc;
     hipStream_t st = (hipStream_t)stream;
+    if (gemm2_w4_takes(plan, K) && ldx % 8 == 0) {
+        int ks = 1;
+        float *part = nullptr, *part2 = nullptr;
+        rc = gemm2_w4_launch(packed, packed2, x, ldx, M, bias, residual, ldr, out, ldo, N, K, epilogue, (float*)workspace, plan, st, &ks,
+                             &part, &part2);
+        if (rc != PARROT_OK || ks == 1) return rc;
+        const int64_t mn = (int64_t)M * N;
+        return launch(K_GEMM_SPLITK, gemm_splitk_epilogue_kernel, dim3((unsigned)((mn + 255) / 256)), dim3(256), 0, st, (const float*)part,
+                      (const float*)part2, ks, M, N, (const bf16_t*)bias, (const bf16_t*)residual, ldr, (bf16_t*)out, ldo, epilogue);
+    }
     const int G = plan.Gs * 32;
     const int64_t n = (int64_t)M * plan.ngroups;
-    rc = launch(K_W4_GEMM, gemm_xsum_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (const bf16_t*)x, ldx, M, K, G,
+    rc = launch(K_GEMM_XSUM, gemm_xsum_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (const bf16_t*)x, ldx, M, K, G,
                 plan.ngroups, (float*)workspace);
     if (rc != PARROT_OK) return rc;
     // the split-K partials follow the activation sums in the workspace

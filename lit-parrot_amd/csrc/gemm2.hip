@@ -17,6 +17,7 @@
 #include <stdlib.h>
 
 #include "parrot_common.h"
+#include "w4_plan.h"
 
 namespace parrot {
 
@@ -229,6 +230,267 @@ int gemm2_launch(const void* W, const void* x, int ldx, int M, const void* bias,
     if (nbuf == 3) PARROT_G2_GO(false, 3);
     PARROT_G2_GO(false, 2);
 #undef PARROT_G2_GO
+}
+
+// ====================================================================================================================
+// int4 (W4K) weights on the same structure: parrot_w4_gemm for prompts (reference quantize/gptq.py:156-201, :254-264).
+//   * A (activations) arrives by LDS-DMA exactly as above;
+//   * B: one 16-byte W4K slice (32 weights of one output row) per thread and half K-step, expanded in registers to the bf16
+//     values 128 + q (exact; ((dword >> 4i) & 0x000F000F) | 0x43004300 is 2 of them) and written to the swizzled slots with
+//     four ds_write_b128 - into the buffer of the NEXT step, after this step's MFMAs;
+//   * at every quantisation-group boundary the group's partial product is folded into the result with the column's scale /
+//     zero and the row's activation sum:  total += scale * (acc - (128 + zero) * sum_g(x)) - the numerics of the decode GEMV
+//     (w4.hip) and of the first-generation kernel.  sum_g(x) comes from a pre-pass in a [group][row] layout, so that a lane's
+//     four consecutive rows of the MFMA C layout are ONE 16-byte load, requested at the start of the group.
+// Takes group sizes that are multiples of 64 (whole K-steps per group); everything else stays on gemm.hip.
+__global__ void __launch_bounds__(256)
+gemm2_xsum_kernel(const bf16_t* __restrict__ x, int ldx, int M, int Mpad, int K, int G, int ngroups, float* __restrict__ xsT) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (int64_t)Mpad * ngroups) return;
+    const int g = (int)(t / Mpad), m = (int)(t % Mpad);
+    float s = 0.f;
+    if (m < M) {
+        const int k0 = g * G, k1 = min(K, k0 + G);
+        const uint4* p = reinterpret_cast<const uint4*>(x + (int64_t)m * ldx + k0);
+        for (int c = 0; c < (k1 - k0) / 8; ++c) {
+            const uint4 v = p[c];
+            s += (bflo(v.x) + bfhi(v.x)) + (bflo(v.y) + bfhi(v.y)) + (bflo(v.z) + bfhi(v.z)) + (bflo(v.w) + bfhi(v.w));
+        }
+    }
+    xsT[t] = s;
+}
+
+template <bool SPLIT, bool SWI>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))
+gemm2_w4_kernel(const bf16_t* __restrict__ A, int lda, int M, const uint4* __restrict__ Wq, const uint4* __restrict__ Wq2, int N,
+                int K, const float* __restrict__ xsT, int Mpad, const bf16_t* __restrict__ bias, const bf16_t* residual, int ldr,
+                bf16_t* out, int ldo, int epi, W4Plan plan, int ksplit, float* __restrict__ part, float* __restrict__ part2, G2Map mp) {
+    __shared__ __attribute__((aligned(1024))) uint4 smem[2][2][G2_TILE16];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    int mt_, nt_, z_;
+    g2_tile_of(mp, blockIdx.x, mt_, nt_, z_);
+    const int m0 = mt_ * G2M, n0 = nt_ * G2N, zsplit = z_;
+    const int lr = lane & 31, lh = lane >> 5;
+    const int ktiles = K / G2K;
+    const int Gt = plan.Gs / 2;  // K-steps per quantisation group
+    const int kt_per = SPLIT ? ktiles / ksplit : ktiles;
+    const int kt_begin = SPLIT ? zsplit * kt_per : 0, kt_end = kt_begin + kt_per;
+
+    const int l_row = lane >> 3, l_slot = lane & 7;
+    const bf16_t* a_src[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int r = (wave * 4 + i) * 8 + l_row;
+        a_src[i] = A + (int64_t)min(m0 + r, M - 1) * lda + (l_slot ^ ((r >> 1) & 7)) * 8;
+    }
+    auto issue_a = [&](int kt, int buf) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a_src[i] + (int64_t)kt * G2K),
+                                             (__attribute__((address_space(3))) void*)&smem[buf][0][(wave * 4 + i) * 64], 16, 0, 0);
+    };
+    // B: thread t stages slice (2 kt + (t & 1)) of row n0 + (t >> 1)
+    const int b_row = tid >> 1, b_half = tid & 1;
+    const int64_t b_rec = (int64_t)min(n0 + b_row, N - 1) * plan.row16;
+    const int b_key = (b_row >> 1) & 7;
+    int a_row[2], c_row[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        a_row[i] = wm * 64 + i * 32 + lr;
+        c_row[i] = wn * 64 + i * 32 + lr;
+    }
+
+    f32x16_t total[2][2];
+    uint32_t gate[SWI && !SPLIT ? 2 : 1][SWI && !SPLIT ? 2 : 1][8];
+    const int npass = SWI ? 2 : 1;
+    for (int pass = 0; pass < npass; ++pass) {
+        const uint4* Wp = pass ? Wq2 : Wq;
+        f32x16_t acc[2][2];
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = total[i][j][r] = 0.f;
+        int slab = 0;
+        uint4 rq;
+        auto fetch_b = [&](int kt) {
+            const int slice = 2 * kt + b_half;
+            while (slab + 1 < plan.nslabs && slice >= plan.slab[slab + 1].slice0) ++slab;
+            rq = Wp[b_rec + plan.slab[slab].w_off16 + (slice - plan.slab[slab].slice0)];
+        };
+        auto stage_b = [&](int buf) {
+            const uint32_t dw[4] = {rq.x, rq.y, rq.z, rq.w};
+#pragma unroll
+            for (int d = 0; d < 4; ++d) {
+                uint32_t o[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) o[i] = ((dw[d] >> (4 * i)) & 0x000F000Fu) | 0x43004300u;
+                smem[buf][1][b_row * 8 + ((b_half * 4 + d) ^ b_key)] = make_uint4(o[0], o[1], o[2], o[3]);
+            }
+        };
+        uint32_t mtg[2];  // {scale, zero} of the current group for this lane's two output columns
+        float4 xs4[2][4];  // activation sums of the current group for this lane's rows of the C layout
+        __syncthreads();   // the previous pass is done with both buffers
+        fetch_b(kt_begin);
+        issue_a(kt_begin, 0);
+        stage_b(0);
+        for (int kt = kt_begin; kt < kt_end; ++kt) {
+            const int buf = (kt - kt_begin) & 1;
+            __syncthreads();  // (vmcnt(0) + lgkmcnt(0) first) A of step kt has landed, B of step kt is written, buffer buf ^ 1 is free
+            if (kt + 1 < kt_end) {
+                issue_a(kt + 1, buf ^ 1);
+                fetch_b(kt + 1);
+            }
+            if (kt % Gt == 0) {  // group start: metadata and activation sums, used Gt steps later
+                const int g = kt / Gt;
+                int gs = 0;
+                while (gs + 1 < plan.nslabs && 2 * kt >= plan.slab[gs + 1].slice0) ++gs;
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const int64_t gn = min(n0 + c_row[j], N - 1);
+                    mtg[j] = reinterpret_cast<const uint32_t*>(Wp + gn * plan.row16 + plan.slab[gs].meta_off16)[g - plan.slab[gs].g0];
+                }
+                const float4* xp = reinterpret_cast<const float4*>(xsT + (int64_t)g * Mpad + m0 + wm * 64 + 4 * lh);
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) xs4[i][q] = xp[(i * 32 + 8 * q) >> 2];
+            }
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                const int slot = ks * 2 + lh;
+                bf16x8_t af[2], bfr[2];
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {
+                    af[i] = __builtin_bit_cast(bf16x8_t, smem[buf][0][a_row[i] * 8 + (slot ^ ((a_row[i] >> 1) & 7))]);
+                    bfr[i] = __builtin_bit_cast(bf16x8_t, smem[buf][1][c_row[i] * 8 + (slot ^ ((c_row[i] >> 1) & 7))]);
+                }
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+            }
+            if (kt + 1 < kt_end) stage_b(buf ^ 1);
+            if ((kt + 1) % Gt == 0) {  // group end: fold
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const float sc = bflo(mtg[j]), zz = 128.0f + bfhi(mtg[j]);
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const float4 x4 = xs4[i][r >> 2];
+                            const float xs = (r & 3) == 0 ? x4.x : ((r & 3) == 1 ? x4.y : ((r & 3) == 2 ? x4.z : x4.w));
+                            total[i][j][r] += sc * (acc[i][j][r] - zz * xs);
+                            acc[i][j][r] = 0.f;
+                        }
+                }
+            }
+        }
+        if constexpr (SPLIT) {
+            float* dst = (pass ? part2 : part) + (int64_t)zsplit * M * N;
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const int col = n0 + c_row[j];
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                        if (row < M && col < N) dst[(int64_t)row * N + col] = total[i][j][r];
+                    }
+                }
+        } else if (SWI && pass == 0) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; r += 2) {
+                        const bf16_t g0 = f2bf(silu(rbf(total[i][j][r]))), g1 = f2bf(silu(rbf(total[i][j][r + 1])));
+                        gate[SWI && !SPLIT ? i : 0][SWI && !SPLIT ? j : 0][r >> 1] = (uint32_t)g0 | ((uint32_t)g1 << 16);
+                    }
+        }
+    }
+    if constexpr (SPLIT) return;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int col = n0 + c_row[j];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                if (row < M && col < N) {
+                    bf16_t o;
+                    if (SWI) {
+                        const uint32_t gp = gate[SWI && !SPLIT ? i : 0][SWI && !SPLIT ? j : 0][r >> 1];
+                        o = f2bf(((r & 1) ? bfhi(gp) : bflo(gp)) * rbf(total[i][j][r]));
+                    } else {
+                        o = apply_epilogue(epi, total[i][j][r], 0.f, bias, residual ? residual + (int64_t)row * ldr : nullptr, col);
+                    }
+                    out[(int64_t)row * ldo + col] = o;
+                }
+            }
+        }
+}
+
+// the int4 kernel takes whole K-steps per group and slab boundaries on K-step boundaries
+bool gemm2_w4_takes(const W4Plan& plan, int K) {
+    if (!gemm2_enabled() || K % G2K != 0 || plan.Gs % 2 != 0) return false;
+    for (int c = 0; c < plan.nslabs; ++c)
+        if (plan.slab[c].slice0 % 2 != 0) return false;
+    return true;
+}
+
+int gemm2_w4_ksplit(int M, int N, int K, const W4Plan& plan) {
+    const int64_t tiles = (int64_t)((M + G2M - 1) / G2M) * ((N + G2N - 1) / G2N);
+    const int ktiles = K / G2K, Gt = plan.Gs / 2;
+    int ks = tiles >= 192 ? 1 : (int)(512 / (tiles > 0 ? tiles : 1));
+    if (ks > 8) ks = 8;
+    while (ks > 1 && (ktiles % (ks * Gt) != 0 || ktiles / ks < 4)) --ks;
+    return ks < 1 ? 1 : ks;
+}
+
+int64_t gemm2_w4_xs_floats(int M, const W4Plan& plan) { return (int64_t)((M + G2M - 1) / G2M) * G2M * plan.ngroups; }
+
+int gemm2_w4_launch(const void* Wq, const void* Wq2, const void* x, int ldx, int M, const void* bias, const void* residual, int ldr,
+                    void* out, int ldo, int N, int K, int epilogue, float* workspace, const W4Plan& plan, hipStream_t st, int* ksplit_out,
+                    float** part_out, float** part2_out) {
+    const int Mpad = (M + G2M - 1) / G2M * G2M;
+    const int64_t nxs = (int64_t)Mpad * plan.ngroups;
+    int rc = launch(K_GEMM_XSUM, gemm2_xsum_kernel, dim3((unsigned)((nxs + 255) / 256)), dim3(256), 0, st, (const bf16_t*)x, ldx, M, Mpad, K,
+                    plan.Gs * 32, plan.ngroups, workspace);
+    if (rc != PARROT_OK) return rc;
+    const int ks = gemm2_w4_ksplit(M, N, K, plan);
+    *ksplit_out = ks;
+    float* part = workspace + nxs;
+    float* part2 = part + (int64_t)ks * M * N;
+    *part_out = part;
+    *part2_out = epilogue == PARROT_EPI_SWIGLU ? part2 : nullptr;
+    G2Map mp;
+    mp.MT = (M + G2M - 1) / G2M;
+    mp.NT = (N + G2N - 1) / G2N;
+    const int64_t total = (int64_t)mp.MT * mp.NT * ks;
+    PARROT_UNSUPPORTED(total < (1ll << 31), "w4_gemm: too many tiles");
+    mp.xcd_ok = (mp.NT % 8 == 0);
+    mp.GM = g2_largest_divisor_le(mp.MT, 8);
+    mp.GN = mp.xcd_ok ? g2_largest_divisor_le(mp.NT / 8, 64 / mp.GM > 0 ? 64 / mp.GM : 1) : 1;
+    const dim3 grid((unsigned)total);
+#define PARROT_G2W_GO(SPLITV, SWIV)                                                                                                 \
+    return launch(K_W4_GEMM, gemm2_w4_kernel<SPLITV, SWIV>, grid, dim3(256), 0, st, (const bf16_t*)x, ldx, M, (const uint4*)Wq,        \
+                  (const uint4*)Wq2, N, K, (const float*)workspace, Mpad, (const bf16_t*)bias, (const bf16_t*)residual, ldr, (bf16_t*)out, \
+                  ldo, epilogue, plan, ks, part, part2, mp)
+    const bool swi = epilogue == PARROT_EPI_SWIGLU;
+    if (ks > 1) {
+        if (swi) PARROT_G2W_GO(true, true);
+        PARROT_G2W_GO(true, false);
+    }
+    if (swi) PARROT_G2W_GO(false, true);
+    PARROT_G2W_GO(false, false);
+#undef PARROT_G2W_GO
 }
 
 }  // namespace parrot

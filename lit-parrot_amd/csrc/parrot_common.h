@@ -72,6 +72,8 @@ enum KernelId : int {
     K_W4C_GEMV,
     K_W4C_GEMV_DUAL,
     K_W4C_DEQUANT,
+    K_GEMM_XSUM,
+    K_GEMM_SPLITK,
     K_COUNT
 };
 

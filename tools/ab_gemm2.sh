@@ -1,6 +1,8 @@
 #!/bin/bash
-# A/B of the LDS-DMA bf16 GEMM's split-K target; StableLM-3B prefill of 512 tokens
-for v in 256 384 512 768 1024; do
-  echo "== T=512 PARROT_GEMM2_SPLIT_TARGET=$v"
-  PARROT_GEMM2_SPLIT_TARGET=$v python tools/prefill_breakdown.py stablelm-base-alpha-3b bf16 512 2>/dev/null | grep -E "bf16_gemm|total"
+# A/B: first-generation GEMMs (PARROT_GEMM2=0) vs the LDS-DMA kernels; Llama-2-7B int4 g128 prefill of 128 / 512 / 2048 tokens
+for T in 128 512 2048; do
+for v in 0 1; do
+  echo "== T=$T PARROT_GEMM2=$v"
+  PARROT_GEMM2=$v python tools/prefill_breakdown.py Llama-2-7b-hf gptq.int4-g128 $T 2>/dev/null | grep -E "w4_gemm|total"
+done
 done
