@@ -235,13 +235,16 @@ int gemm2_launch(const void* W, const void* x, int ldx, int M, const void* bias,
 // ====================================================================================================================
 // int4 (W4K) weights on the same structure: parrot_w4_gemm for prompts (reference quantize/gptq.py:156-201, :254-264).
 //   * A (activations) arrives by LDS-DMA exactly as above;
-//   * B: one 16-byte W4K slice (32 weights of one output row) per thread and half K-step, expanded in registers to the bf16
-//     values 128 + q (exact; ((dword >> 4i) & 0x000F000F) | 0x43004300 is 2 of them) and written to the swizzled slots with
-//     four ds_write_b128 - into the buffer of the NEXT step, after this step's MFMAs;
+//   * B stays PACKED in LDS (LDS-DMA too: 4 KB per K-step instead of 16): a lane's B fragments of one K-step are the four
+//     dwords of one W4K slice - one ds_read_b128 - each expanded in registers to eight bf16 values 128 + q (exact;
+//     ((dword >> 4i) & 0x000F000F) | 0x43004300 is two of them) right in front of its MFMA.  No register staging, no
+//     ds_write pass, and a ring of three stages fits twice on a CU (first version: registers -> expand -> ds_write_b128 x 4 into
+//     a bf16 image with a one-deep prefetch; at 128 rows every K-step then waited a full HBM latency);
 //   * at every quantisation-group boundary the group's partial product is folded into the result with the column's scale /
 //     zero and the row's activation sum:  total += scale * (acc - (128 + zero) * sum_g(x)) - the numerics of the decode GEMV
-//     (w4.hip) and of the first-generation kernel.  sum_g(x) comes from a pre-pass in a [group][row] layout, so that a lane's
-//     four consecutive rows of the MFMA C layout are ONE 16-byte load, requested at the start of the group.
+//     (w4.hip) and of the first-generation kernel.  sum_g(x) comes from a pre-pass in a [group][row] layout; the sums and the
+//     {scale, zero} words of a group reach LDS by 4-byte LDS-DMA one group ahead (no VGPR-destination load in the loop: the
+//     compiler would answer one with vmcnt(0) and drain the ring).
 // Takes group sizes that are multiples of 64 (whole K-steps per group); everything else stays on gemm.hip.
 __global__ void __launch_bounds__(256)
 gemm2_xsum_kernel(const bf16_t* __restrict__ x, int ldx, int M, int Mpad, int K, int G, int ngroups, float* __restrict__ xsT) {
@@ -260,12 +263,38 @@ gemm2_xsum_kernel(const bf16_t* __restrict__ x, int ldx, int M, int Mpad, int K,
     xsT[t] = s;
 }
 
+// LDS-DMA issued from inline asm.  With the builtin, hipcc put an s_waitcnt vmcnt(0) in front of the first fragment read of every
+// K-step of the int4 kernel (it cannot prove that the stage being read is not the stage in flight) and the ring drained every
+// step; an asm load is absent from its bookkeeping, and the loop below counts vmcnt itself.  M0 = the wave's LDS byte address.
+__device__ __forceinline__ void glds16_asm(const void* gsrc, const void* lds_dst_uniform) {
+    unsigned keep;
+    const unsigned dst = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)lds_dst_uniform);
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(gsrc), "s"(dst)
+                 : "memory");
+}
+__device__ __forceinline__ void glds4_asm(const void* gsrc, const void* lds_dst_uniform) {
+    unsigned keep;
+    const unsigned dst = __builtin_amdgcn_readfirstlane((unsigned)(uintptr_t)lds_dst_uniform);
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dword %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(gsrc), "s"(dst)
+                 : "memory");
+}
+
+// LDS of the int4 kernel (16-byte units): ring of 3 stages {A image 128 x 8 slots, packed B 128 rows x 2 slices} + two
+// parities of group metadata {128 activation sums fp32, 128 {scale, zero} words}: 63.5 KB, two workgroups per CU.
+constexpr int W4_STAGE16 = G2_TILE16 + 256;
+constexpr int W4_NBUF = 3;
+constexpr int W4_META16 = 64;
+
 template <bool SPLIT, bool SWI>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))
 gemm2_w4_kernel(const bf16_t* __restrict__ A, int lda, int M, const uint4* __restrict__ Wq, const uint4* __restrict__ Wq2, int N,
                 int K, const float* __restrict__ xsT, int Mpad, const bf16_t* __restrict__ bias, const bf16_t* residual, int ldr,
                 bf16_t* out, int ldo, int epi, W4Plan plan, int ksplit, float* __restrict__ part, float* __restrict__ part2, G2Map mp) {
-    __shared__ __attribute__((aligned(1024))) uint4 smem[2][2][G2_TILE16];
+    __shared__ __attribute__((aligned(1024))) uint4 smem[W4_NBUF * W4_STAGE16 + 2 * W4_META16];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
     int mt_, nt_, z_;
@@ -276,7 +305,10 @@ gemm2_w4_kernel(const bf16_t* __restrict__ A, int lda, int M, const uint4* __res
     const int Gt = plan.Gs / 2;  // K-steps per quantisation group
     const int kt_per = SPLIT ? ktiles / ksplit : ktiles;
     const int kt_begin = SPLIT ? zsplit * kt_per : 0, kt_end = kt_begin + kt_per;
+    const int g_end = (kt_end + Gt - 1) / Gt;
 
+    // ---- LDS-DMA sources.  Everything this kernel reads from global memory inside the K loop goes straight to LDS, so that all
+    // outstanding loads are counted on vmcnt in issue order and waited for with exact counts (5 per wave and K-step).
     const int l_row = lane >> 3, l_slot = lane & 7;
     const bf16_t* a_src[4];
 #pragma unroll
@@ -284,22 +316,24 @@ gemm2_w4_kernel(const bf16_t* __restrict__ A, int lda, int M, const uint4* __res
         const int r = (wave * 4 + i) * 8 + l_row;
         a_src[i] = A + (int64_t)min(m0 + r, M - 1) * lda + (l_slot ^ ((r >> 1) & 7)) * 8;
     }
-    auto issue_a = [&](int kt, int buf) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a_src[i] + (int64_t)kt * G2K),
-                                             (__attribute__((address_space(3))) void*)&smem[buf][0][(wave * 4 + i) * 64], 16, 0, 0);
-    };
-    // B: thread t stages slice (2 kt + (t & 1)) of row n0 + (t >> 1)
-    const int b_row = tid >> 1, b_half = tid & 1;
-    const int64_t b_rec = (int64_t)min(n0 + b_row, N - 1) * plan.row16;
-    const int b_key = (b_row >> 1) & 7;
-    int a_row[2], c_row[2];
+    // packed B: wave w brings rows 32 w .. 32 w + 31, lane l the 16-byte unit l of that KB: row 32 w + l / 2, physical half l % 2,
+    // which holds slice 2 kt + (half ^ ((row >> 3) & 1)) - rows 8 apart swap halves, so that the 16 lanes of a ds_read_b128 group
+    // (one row each, same half) land on 16 different 16-byte slots
+    const int bl_row = wave * 32 + (lane >> 1);
+    const int bl_half = (lane & 1) ^ ((bl_row >> 3) & 1);
+    const int64_t bl_rec = (int64_t)min(n0 + bl_row, N - 1) * plan.row16 + bl_half;
+    // metadata: waves 0, 1 bring the activation sums of rows 64 w + lane, waves 2, 3 the {scale, zero} words of columns 64 (w - 2) + lane
+    const int64_t ml_rec = (int64_t)min(n0 + (wave & 1) * 64 + lane, N - 1) * plan.row16;
+    const float* xs_src = xsT + m0 + (wave & 1) * 64 + lane;
+
+    int a_row[2], c_row[2], b_unit[2];
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
         a_row[i] = wm * 64 + i * 32 + lr;
         c_row[i] = wn * 64 + i * 32 + lr;
+        b_unit[i] = c_row[i] * 2 + (lh ^ ((c_row[i] >> 3) & 1));
     }
+    uint4* const meta = smem + W4_NBUF * W4_STAGE16;
 
     f32x16_t total[2][2];
     uint32_t gate[SWI && !SPLIT ? 2 : 1][SWI && !SPLIT ? 2 : 1][8];
@@ -313,70 +347,83 @@ gemm2_w4_kernel(const bf16_t* __restrict__ A, int lda, int M, const uint4* __res
             for (int j = 0; j < 2; ++j)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[i][j][r] = total[i][j][r] = 0.f;
-        int slab = 0;
-        uint4 rq;
-        auto fetch_b = [&](int kt) {
-            const int slice = 2 * kt + b_half;
-            while (slab + 1 < plan.nslabs && slice >= plan.slab[slab + 1].slice0) ++slab;
-            rq = Wp[b_rec + plan.slab[slab].w_off16 + (slice - plan.slab[slab].slice0)];
-        };
-        auto stage_b = [&](int buf) {
-            const uint32_t dw[4] = {rq.x, rq.y, rq.z, rq.w};
+        int slab = 0;  // slab of the K-step being issued (issue order is monotone)
+        auto issue_tile = [&](int kt, int buf) {
+            while (slab + 1 < plan.nslabs && 2 * kt >= plan.slab[slab + 1].slice0) ++slab;
+            uint4* st = smem + buf * W4_STAGE16;
 #pragma unroll
-            for (int d = 0; d < 4; ++d) {
-                uint32_t o[4];
-#pragma unroll
-                for (int i = 0; i < 4; ++i) o[i] = ((dw[d] >> (4 * i)) & 0x000F000Fu) | 0x43004300u;
-                smem[buf][1][b_row * 8 + ((b_half * 4 + d) ^ b_key)] = make_uint4(o[0], o[1], o[2], o[3]);
-            }
+            for (int i = 0; i < 4; ++i)
+                glds16_asm(a_src[i] + (int64_t)kt * G2K, st + (wave * 4 + i) * 64);
+            const uint4* bsrc = Wp + bl_rec + plan.slab[slab].w_off16 + (2 * kt - plan.slab[slab].slice0);
+            glds16_asm(bsrc, st + G2_TILE16 + wave * 64);
         };
-        uint32_t mtg[2];  // {scale, zero} of the current group for this lane's two output columns
-        float4 xs4[2][4];  // activation sums of the current group for this lane's rows of the C layout
-        __syncthreads();   // the previous pass is done with both buffers
-        fetch_b(kt_begin);
-        issue_a(kt_begin, 0);
-        stage_b(0);
-        for (int kt = kt_begin; kt < kt_end; ++kt) {
-            const int buf = (kt - kt_begin) & 1;
-            __syncthreads();  // (vmcnt(0) + lgkmcnt(0) first) A of step kt has landed, B of step kt is written, buffer buf ^ 1 is free
-            if (kt + 1 < kt_end) {
-                issue_a(kt + 1, buf ^ 1);
-                fetch_b(kt + 1);
-            }
-            if (kt % Gt == 0) {  // group start: metadata and activation sums, used Gt steps later
-                const int g = kt / Gt;
+        auto issue_meta = [&](int g) {  // one 4-byte LDS-DMA per wave
+            uint4* mb = meta + (g & 1) * W4_META16;
+            if (wave < 2) {
+                glds4_asm(xs_src + (int64_t)g * Mpad, reinterpret_cast<float*>(mb) + wave * 64);
+            } else {
                 int gs = 0;
-                while (gs + 1 < plan.nslabs && 2 * kt >= plan.slab[gs + 1].slice0) ++gs;
-#pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    const int64_t gn = min(n0 + c_row[j], N - 1);
-                    mtg[j] = reinterpret_cast<const uint32_t*>(Wp + gn * plan.row16 + plan.slab[gs].meta_off16)[g - plan.slab[gs].g0];
-                }
-                const float4* xp = reinterpret_cast<const float4*>(xsT + (int64_t)g * Mpad + m0 + wm * 64 + 4 * lh);
-#pragma unroll
-                for (int i = 0; i < 2; ++i)
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) xs4[i][q] = xp[(i * 32 + 8 * q) >> 2];
+                while (gs + 1 < plan.nslabs && 2 * g * Gt >= plan.slab[gs + 1].slice0) ++gs;
+                const uint32_t* msrc = reinterpret_cast<const uint32_t*>(Wp + ml_rec + plan.slab[gs].meta_off16) + (g - plan.slab[gs].g0);
+                glds4_asm(msrc, reinterpret_cast<uint32_t*>(mb + 32) + (wave - 2) * 64);
             }
+        };
+        // Ring of three stages; per wave and K-step 5 LDS-DMA loads, retired in issue order.  Before the barrier of step t each wave
+        // waits until only the 5 loads of step t+1 may be outstanding: its pieces of step t (and any metadata issued before) have
+        // landed; past the barrier everybody's have, and the stage of step t-1 is free for step t+2.  The metadata of group g+1 is
+        // issued at the start of group g (before that step's tile, so that the 5 newest loads are always exactly a tile) into the
+        // other parity, which the fold of group g-1 finished reading before this step's barrier.
+        __syncthreads();  // previous pass done with the stages and the metadata
+        issue_meta(kt_begin / Gt);
+        issue_tile(kt_begin, 0);
+        if (kt_begin + 1 < kt_end) issue_tile(kt_begin + 1, 1);
+        int buf = 0;
+        for (int kt = kt_begin; kt < kt_end; ++kt) {
+            if (kt + 1 < kt_end)
+                asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+            else
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+            const int g = kt / Gt;
+            if (kt % Gt == 0 && g + 1 < g_end) issue_meta(g + 1);
+            if (kt + 2 < kt_end) issue_tile(kt + 2, buf >= 1 ? buf - 1 : W4_NBUF - 1);
+            const uint4* sa = smem + buf * W4_STAGE16;
+            const uint4* sb = sa + G2_TILE16;
+            // this lane's 2 x 4 dwords of packed weights: k-block lh * 4 + ks of the step goes to MFMA ks (any assignment of the
+            // step's eight 8-k blocks to (MFMA, lane half) is valid as long as A uses the same one)
+            const uint4 bq0 = sb[b_unit[0]], bq1 = sb[b_unit[1]];
+            const uint32_t bw[2][4] = {{bq0.x, bq0.y, bq0.z, bq0.w}, {bq1.x, bq1.y, bq1.z, bq1.w}};
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
-                const int slot = ks * 2 + lh;
+                const int slot = lh * 4 + ks;
                 bf16x8_t af[2], bfr[2];
 #pragma unroll
                 for (int i = 0; i < 2; ++i) {
-                    af[i] = __builtin_bit_cast(bf16x8_t, smem[buf][0][a_row[i] * 8 + (slot ^ ((a_row[i] >> 1) & 7))]);
-                    bfr[i] = __builtin_bit_cast(bf16x8_t, smem[buf][1][c_row[i] * 8 + (slot ^ ((c_row[i] >> 1) & 7))]);
+                    af[i] = __builtin_bit_cast(bf16x8_t, sa[a_row[i] * 8 + (slot ^ ((a_row[i] >> 1) & 7))]);
+                    uint32_t o[4];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) o[q] = ((bw[i][ks] >> (4 * q)) & 0x000F000Fu) | 0x43004300u;
+                    bfr[i] = __builtin_bit_cast(bf16x8_t, make_uint4(o[0], o[1], o[2], o[3]));
                 }
 #pragma unroll
                 for (int i = 0; i < 2; ++i)
 #pragma unroll
                     for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
             }
-            if (kt + 1 < kt_end) stage_b(buf ^ 1);
-            if ((kt + 1) % Gt == 0) {  // group end: fold
+            if ((kt + 1) % Gt == 0 || kt + 1 == kt_end) {  // group end: fold
+                const uint4* mb = meta + (g & 1) * W4_META16;
+                const float* xs_l = reinterpret_cast<const float*>(mb);
+                const uint32_t* mt_l = reinterpret_cast<const uint32_t*>(mb + 32);
+                float4 xs4[2][4];
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) xs4[i][q] = *reinterpret_cast<const float4*>(xs_l + wm * 64 + i * 32 + 8 * q + 4 * lh);
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
-                    const float sc = bflo(mtg[j]), zz = 128.0f + bfhi(mtg[j]);
+                    const uint32_t mt = mt_l[c_row[j]];
+                    const float sc = bflo(mt), zz = 128.0f + bfhi(mt);
 #pragma unroll
                     for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -388,6 +435,7 @@ gemm2_w4_kernel(const bf16_t* __restrict__ A, int lda, int M, const uint4* __res
                         }
                 }
             }
+            buf = buf + 1 == W4_NBUF ? 0 : buf + 1;
         }
         if constexpr (SPLIT) {
             float* dst = (pass ? part2 : part) + (int64_t)zsplit * M * N;
