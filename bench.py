@@ -31,6 +31,7 @@ REPO = Path(__file__).resolve().parent
 if str(REPO) not in sys.path:
     sys.path.insert(0, str(REPO))
 
+MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense bf16 (MI355X_MICROARCH.md; the headline figures with 2:1 sparsity are not used)
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s spec, ~6.3 TB/s achievable)
 
 WORKLOADS = {
@@ -253,6 +254,7 @@ def main() -> None:
                     "bytes_per_launch": bytes_per_launch,
                     "avg_launch_us": avg_s * 1e6, "launches_per_token": kb[dom][1]}
     step_gbs = (w_bytes + kv_bytes) / (ms_per_step * 1e-3) / 1e9
+    prefill_flops = 2.0 * cfg.n_linear_params() * T - 2.0 * cfg.padded_vocab_size * cfg.n_embd * (T - 1)
 
     result = {
         "metric": "decode tokens/s (single-stream per GPU, independent replicas)",
@@ -279,6 +281,10 @@ def main() -> None:
         "reference_definition_tokens_per_s": (args.warmup + args.steps + 1) / (t_pre + (args.warmup + args.steps) * ms_per_step * 1e-3),
         "prefill_ms": t_pre * 1e3,
         "prefill_tokens_per_s": T / t_pre,
+        # the prompt's Linears against the dense bf16 matrix peak (int4 / int8 weights are multiplied as bf16 / int8 MFMA operands);
+        # whole-prefill wall time, attention and norms included in the denominator, lm_head counted for the last row only
+        "prefill_roofline": {"bound": "mfma", "achieved": prefill_flops / t_pre / 1e12, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
+                             "frac": prefill_flops / t_pre / 1e12 / MFMA_BF16_PEAK_TFLOPS, "linear_flops": prefill_flops},
         "build_s": t_build,
     }
     if rank == 0:

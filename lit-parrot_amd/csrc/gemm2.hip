@@ -72,8 +72,9 @@ gemm2_kernel(const bf16_t* __restrict__ A, int lda, int M, const bf16_t* __restr
     const int m0 = mt_ * G2M, n0 = nt_ * G2N, zsplit = z_;
     const int lr = lane & 31, lh = lane >> 5;
     const int ktiles = K / G2K;
-    const int kt_per = SPLIT ? ktiles / ksplit : ktiles;
-    const int kt_begin = SPLIT ? zsplit * kt_per : 0, kt_end = kt_begin + kt_per;
+    // split z owns K-steps [z * ktiles / ksplit, (z + 1) * ktiles / ksplit): the ranges need not be equal
+    const int kt_begin = SPLIT ? (int)((int64_t)zsplit * ktiles / ksplit) : 0;
+    const int kt_end = SPLIT ? (int)((int64_t)(zsplit + 1) * ktiles / ksplit) : ktiles;
 
     // LDS-DMA assignment: a tile is 16 wave-instructions of 8 rows; wave w issues instructions 4w .. 4w+3 of A and of B.
     // Lane l of an instruction: row r = r0 + l / 8, LDS slot l % 8 <- global slot (l % 8) ^ ((r >> 1) & 7).
@@ -179,7 +180,7 @@ int gemm2_ksplit(int M, int N, int K) {
     }
     int ks = tiles >= 192 ? 1 : (int)(target / (tiles > 0 ? tiles : 1));
     if (ks > 8) ks = 8;
-    while (ks > 1 && (ktiles % ks != 0 || ktiles / ks < 8)) --ks;
+    while (ks > 1 && ktiles / ks < 8) --ks;  // (uneven ranges are fine: split z owns steps [z kt / ks, (z + 1) kt / ks))
     return ks < 1 ? 1 : ks;
 }
 
@@ -285,35 +286,44 @@ __device__ __forceinline__ void glds4_asm(const void* gsrc, const void* lds_dst_
 
 // LDS of the int4 kernel (16-byte units): ring of 3 stages {A image 128 x 8 slots, packed B 128 rows x 2 slices} + two
 // parities of group metadata {128 activation sums fp32, 128 {scale, zero} words}: 63.5 KB, two workgroups per CU.
-constexpr int W4_STAGE16 = G2_TILE16 + 256;
-constexpr int W4_NBUF = 3;
-constexpr int W4_META16 = 64;
-
-template <bool SPLIT, bool SWI>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))
+// WN = wave columns: 2 -> 128 x 128 tile, 4 waves, ring of 3 stages, two workgroups per CU (63.5 KB each);
+//                    4 -> 128 x 256 tile, 8 waves, ring of 6 stages, one workgroup per CU (147 KB): for launches with ONE m-tile
+//                         (prompts up to 128 rows), which are bound by the weight stream - a third of every stage comes from HBM
+//                         instead of a fifth, and five stages are in flight instead of two.
+template <bool SPLIT, bool SWI, int WN>
+__global__ void __launch_bounds__(WN * 128) __attribute__((amdgpu_waves_per_eu(2, 2)))
 gemm2_w4_kernel(const bf16_t* __restrict__ A, int lda, int M, const uint4* __restrict__ Wq, const uint4* __restrict__ Wq2, int N,
                 int K, const float* __restrict__ xsT, int Mpad, const bf16_t* __restrict__ bias, const bf16_t* residual, int ldr,
                 bf16_t* out, int ldo, int epi, W4Plan plan, int ksplit, float* __restrict__ part, float* __restrict__ part2, G2Map mp) {
+    constexpr int TN = WN * 64;                      // tile columns
+    constexpr int NWAVES = 2 * WN;
+    constexpr int W4_NBUF = WN == 2 ? 3 : 6;
+    constexpr int W4_STAGE16 = G2_TILE16 + TN * 2;   // A image + packed B (two 16-byte slices per row)
+    constexpr int W4_META16 = 32 + TN / 4;           // 128 activation sums + TN {scale, zero} words
+    constexpr int A_PER_WAVE = 16 / NWAVES;          // 1-KB LDS-DMA pieces of the A tile per wave
+    constexpr int TILE_LOADS = A_PER_WAVE + 1;       // LDS-DMA loads per wave and K-step
     __shared__ __attribute__((aligned(1024))) uint4 smem[W4_NBUF * W4_STAGE16 + 2 * W4_META16];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave / WN, wn = wave % WN;
     int mt_, nt_, z_;
     g2_tile_of(mp, blockIdx.x, mt_, nt_, z_);
-    const int m0 = mt_ * G2M, n0 = nt_ * G2N, zsplit = z_;
+    const int m0 = mt_ * G2M, n0 = nt_ * TN, zsplit = z_;
     const int lr = lane & 31, lh = lane >> 5;
     const int ktiles = K / G2K;
     const int Gt = plan.Gs / 2;  // K-steps per quantisation group
-    const int kt_per = SPLIT ? ktiles / ksplit : ktiles;
-    const int kt_begin = SPLIT ? zsplit * kt_per : 0, kt_end = kt_begin + kt_per;
+    // split z owns the whole quantisation groups [z * G / ksplit, (z + 1) * G / ksplit) (G = number of groups): ranges need not be equal
+    const int G_all = (ktiles + Gt - 1) / Gt;
+    const int kt_begin = SPLIT ? (int)((int64_t)zsplit * G_all / ksplit) * Gt : 0;
+    const int kt_end = SPLIT ? min((int)((int64_t)(zsplit + 1) * G_all / ksplit) * Gt, ktiles) : ktiles;
     const int g_end = (kt_end + Gt - 1) / Gt;
 
     // ---- LDS-DMA sources.  Everything this kernel reads from global memory inside the K loop goes straight to LDS, so that all
     // outstanding loads are counted on vmcnt in issue order and waited for with exact counts (5 per wave and K-step).
     const int l_row = lane >> 3, l_slot = lane & 7;
-    const bf16_t* a_src[4];
+    const bf16_t* a_src[A_PER_WAVE];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int r = (wave * 4 + i) * 8 + l_row;
+    for (int i = 0; i < A_PER_WAVE; ++i) {
+        const int r = (wave * A_PER_WAVE + i) * 8 + l_row;
         a_src[i] = A + (int64_t)min(m0 + r, M - 1) * lda + (l_slot ^ ((r >> 1) & 7)) * 8;
     }
     // packed B: wave w brings rows 32 w .. 32 w + 31, lane l the 16-byte unit l of that KB: row 32 w + l / 2, physical half l % 2,
@@ -323,7 +333,7 @@ gemm2_w4_kernel(const bf16_t* __restrict__ A, int lda, int M, const uint4* __res
     const int bl_half = (lane & 1) ^ ((bl_row >> 3) & 1);
     const int64_t bl_rec = (int64_t)min(n0 + bl_row, N - 1) * plan.row16 + bl_half;
     // metadata: waves 0, 1 bring the activation sums of rows 64 w + lane, waves 2, 3 the {scale, zero} words of columns 64 (w - 2) + lane
-    const int64_t ml_rec = (int64_t)min(n0 + (wave & 1) * 64 + lane, N - 1) * plan.row16;
+    const int64_t ml_rec = (int64_t)min(n0 + max(wave - 2, 0) * 64 + lane, N - 1) * plan.row16;
     const float* xs_src = xsT + m0 + (wave & 1) * 64 + lane;
 
     int a_row[2], c_row[2], b_unit[2];
@@ -352,8 +362,8 @@ gemm2_w4_kernel(const bf16_t* __restrict__ A, int lda, int M, const uint4* __res
             while (slab + 1 < plan.nslabs && 2 * kt >= plan.slab[slab + 1].slice0) ++slab;
             uint4* st = smem + buf * W4_STAGE16;
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
-                glds16_asm(a_src[i] + (int64_t)kt * G2K, st + (wave * 4 + i) * 64);
+            for (int i = 0; i < A_PER_WAVE; ++i)
+                glds16_asm(a_src[i] + (int64_t)kt * G2K, st + (wave * A_PER_WAVE + i) * 64);
             const uint4* bsrc = Wp + bl_rec + plan.slab[slab].w_off16 + (2 * kt - plan.slab[slab].slice0);
             glds16_asm(bsrc, st + G2_TILE16 + wave * 64);
         };
@@ -361,33 +371,42 @@ gemm2_w4_kernel(const bf16_t* __restrict__ A, int lda, int M, const uint4* __res
             uint4* mb = meta + (g & 1) * W4_META16;
             if (wave < 2) {
                 glds4_asm(xs_src + (int64_t)g * Mpad, reinterpret_cast<float*>(mb) + wave * 64);
-            } else {
+            } else if (wave < 2 + WN) {
                 int gs = 0;
                 while (gs + 1 < plan.nslabs && 2 * g * Gt >= plan.slab[gs + 1].slice0) ++gs;
                 const uint32_t* msrc = reinterpret_cast<const uint32_t*>(Wp + ml_rec + plan.slab[gs].meta_off16) + (g - plan.slab[gs].g0);
                 glds4_asm(msrc, reinterpret_cast<uint32_t*>(mb + 32) + (wave - 2) * 64);
             }
         };
-        // Ring of three stages; per wave and K-step 5 LDS-DMA loads, retired in issue order.  Before the barrier of step t each wave
-        // waits until only the 5 loads of step t+1 may be outstanding: its pieces of step t (and any metadata issued before) have
-        // landed; past the barrier everybody's have, and the stage of step t-1 is free for step t+2.  The metadata of group g+1 is
-        // issued at the start of group g (before that step's tile, so that the 5 newest loads are always exactly a tile) into the
-        // other parity, which the fold of group g-1 finished reading before this step's barrier.
+        // Ring of NBUF stages; per wave and K-step TILE_LOADS LDS-DMA loads, retired in issue order.  Before the barrier of step t
+        // each wave waits until only the loads of steps t+1 .. t+NBUF-2 may be outstanding: its pieces of step t (and any metadata
+        // issued before) have landed; past the barrier everybody's have, and the stage of step t-1 is free for step t+NBUF-1.  The
+        // metadata of group g+1 is issued at the start of group g (before that step's tile, so that the newest loads are always
+        // whole tiles) into the other parity, which the fold of group g-1 finished reading before this step's barrier.
         __syncthreads();  // previous pass done with the stages and the metadata
         issue_meta(kt_begin / Gt);
-        issue_tile(kt_begin, 0);
-        if (kt_begin + 1 < kt_end) issue_tile(kt_begin + 1, 1);
+#pragma unroll
+        for (int d = 0; d < W4_NBUF - 1; ++d)
+            if (kt_begin + d < kt_end) issue_tile(kt_begin + d, d);
         int buf = 0;
         for (int kt = kt_begin; kt < kt_end; ++kt) {
-            if (kt + 1 < kt_end)
-                asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+            // tiles still allowed in flight: min(NBUF - 2, steps left after this one); the count is an immediate
+            const int ahead = min(W4_NBUF - 2, kt_end - 1 - kt);
+            if (ahead >= 4)
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * TILE_LOADS) : "memory");
+            else if (ahead == 3)
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * TILE_LOADS) : "memory");
+            else if (ahead == 2)
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * TILE_LOADS) : "memory");
+            else if (ahead == 1)
+                asm volatile("s_waitcnt vmcnt(%0)" ::"n"(1 * TILE_LOADS) : "memory");
             else
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
             const int g = kt / Gt;
             if (kt % Gt == 0 && g + 1 < g_end) issue_meta(g + 1);
-            if (kt + 2 < kt_end) issue_tile(kt + 2, buf >= 1 ? buf - 1 : W4_NBUF - 1);
+            if (kt + W4_NBUF - 1 < kt_end) issue_tile(kt + W4_NBUF - 1, buf >= 1 ? buf - 1 : W4_NBUF - 1);
             const uint4* sa = smem + buf * W4_STAGE16;
             const uint4* sb = sa + G2_TILE16;
             // this lane's 2 x 4 dwords of packed weights: k-block lh * 4 + ks of the step goes to MFMA ks (any assignment of the
@@ -493,12 +512,27 @@ bool gemm2_w4_takes(const W4Plan& plan, int K) {
     return true;
 }
 
+// one m-tile (prompts up to 128 rows): the 128 x 256 / 8-wave / 6-stage shape
+int gemm2_w4_wn(int M) {
+    static int env = -1;  // PARROT_GEMM2_W4_WN = 2 | 4 (A/B)
+    if (env < 0) {
+        const char* e = getenv("PARROT_GEMM2_W4_WN");
+        env = e ? atoi(e) : 0;
+    }
+    if (env == 2 || env == 4) return env;
+    return M <= G2M ? 4 : 2;
+}
+
 int gemm2_w4_ksplit(int M, int N, int K, const W4Plan& plan) {
-    const int64_t tiles = (int64_t)((M + G2M - 1) / G2M) * ((N + G2N - 1) / G2N);
+    const int wn = gemm2_w4_wn(M);
+    const int tn = wn * 64;
+    const int64_t tiles = (int64_t)((M + G2M - 1) / G2M) * ((N + tn - 1) / tn);
     const int ktiles = K / G2K, Gt = plan.Gs / 2;
-    int ks = tiles >= 192 ? 1 : (int)(512 / (tiles > 0 ? tiles : 1));
+    const int target = wn == 4 ? 256 : 512;  // workgroups that fill the chip
+    int ks = tiles >= (wn == 4 ? 128 : 192) ? 1 : (int)(target / (tiles > 0 ? tiles : 1));
     if (ks > 8) ks = 8;
-    while (ks > 1 && (ktiles % (ks * Gt) != 0 || ktiles / ks < 4)) --ks;
+    const int G_all = (ktiles + Gt - 1) / Gt;
+    while (ks > 1 && (G_all / ks < 1 || ktiles / ks < 4)) --ks;  // whole groups per split, ranges need not be equal
     return ks < 1 ? 1 : ks;
 }
 
@@ -518,26 +552,36 @@ int gemm2_w4_launch(const void* Wq, const void* Wq2, const void* x, int ldx, int
     float* part2 = part + (int64_t)ks * M * N;
     *part_out = part;
     *part2_out = epilogue == PARROT_EPI_SWIGLU ? part2 : nullptr;
+    const int wn = gemm2_w4_wn(M);
     G2Map mp;
     mp.MT = (M + G2M - 1) / G2M;
-    mp.NT = (N + G2N - 1) / G2N;
+    mp.NT = (N + wn * 64 - 1) / (wn * 64);
     const int64_t total = (int64_t)mp.MT * mp.NT * ks;
     PARROT_UNSUPPORTED(total < (1ll << 31), "w4_gemm: too many tiles");
+    const int resident_per_xcd = wn == 4 ? 32 : 64;
     mp.xcd_ok = (mp.NT % 8 == 0);
     mp.GM = g2_largest_divisor_le(mp.MT, 8);
-    mp.GN = mp.xcd_ok ? g2_largest_divisor_le(mp.NT / 8, 64 / mp.GM > 0 ? 64 / mp.GM : 1) : 1;
+    mp.GN = mp.xcd_ok ? g2_largest_divisor_le(mp.NT / 8, resident_per_xcd / mp.GM > 0 ? resident_per_xcd / mp.GM : 1) : 1;
     const dim3 grid((unsigned)total);
-#define PARROT_G2W_GO(SPLITV, SWIV)                                                                                                 \
-    return launch(K_W4_GEMM, gemm2_w4_kernel<SPLITV, SWIV>, grid, dim3(256), 0, st, (const bf16_t*)x, ldx, M, (const uint4*)Wq,        \
+#define PARROT_G2W_GO(SPLITV, SWIV, WNV)                                                                                            \
+    return launch(K_W4_GEMM, gemm2_w4_kernel<SPLITV, SWIV, WNV>, grid, dim3(WNV * 128), 0, st, (const bf16_t*)x, ldx, M, (const uint4*)Wq, \
                   (const uint4*)Wq2, N, K, (const float*)workspace, Mpad, (const bf16_t*)bias, (const bf16_t*)residual, ldr, (bf16_t*)out, \
                   ldo, epilogue, plan, ks, part, part2, mp)
     const bool swi = epilogue == PARROT_EPI_SWIGLU;
-    if (ks > 1) {
-        if (swi) PARROT_G2W_GO(true, true);
-        PARROT_G2W_GO(true, false);
+    if (wn == 4) {
+        if (ks > 1) {
+            if (swi) PARROT_G2W_GO(true, true, 4);
+            PARROT_G2W_GO(true, false, 4);
+        }
+        if (swi) PARROT_G2W_GO(false, true, 4);
+        PARROT_G2W_GO(false, false, 4);
     }
-    if (swi) PARROT_G2W_GO(false, true);
-    PARROT_G2W_GO(false, false);
+    if (ks > 1) {
+        if (swi) PARROT_G2W_GO(true, true, 2);
+        PARROT_G2W_GO(true, false, 2);
+    }
+    if (swi) PARROT_G2W_GO(false, true, 2);
+    PARROT_G2W_GO(false, false, 2);
 #undef PARROT_G2W_GO
 }
 

@@ -11,13 +11,13 @@ echo "== bench (no profiler)"
 if [ "$SKIP_BENCH" != "1" ]; then
 timeout -k 10 400 python bench.py --steps 256 > $OUT/llama2-7b-int4_bench.json 2> $OUT/llama2-7b-int4_bench.err || exit 1
 tail -c 400 $OUT/llama2-7b-int4_bench.json; echo
-for w in llama2-7b-int8 stablelm-3b-bf16 falcon-40b-int4 pythia-160m-bf16; do
+for w in llama2-7b-int8 llama2-7b-nf4 stablelm-3b-bf16 falcon-40b-int4 pythia-160m-bf16; do
   timeout -k 10 600 python bench.py --workload $w --steps 128 --no-cpu-baseline > $OUT/${w}_bench.json 2> $OUT/${w}_bench.err || exit 1
   echo "$w done"
 done
 fi
 echo "== rocprofv3 kernel stats"
-for w in llama2-7b-int4 llama2-7b-int8 stablelm-3b-bf16 falcon-40b-int4; do
+for w in llama2-7b-int4 llama2-7b-int8 llama2-7b-nf4 stablelm-3b-bf16 falcon-40b-int4; do
   timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_$w -o $w -- python3 bench.py --workload $w --steps 64 --no-cpu-baseline > $OUT/prof_${w}.log 2>&1 || exit 1
   echo "$w profiled"
 done
