@@ -512,15 +512,17 @@ bool gemm2_w4_takes(const W4Plan& plan, int K) {
     return true;
 }
 
-// one m-tile (prompts up to 128 rows): the 128 x 256 / 8-wave / 6-stage shape
+// tile shape of the int4 kernel (wave columns)
 int gemm2_w4_wn(int M) {
     static int env = -1;  // PARROT_GEMM2_W4_WN = 2 | 4 (A/B)
     if (env < 0) {
         const char* e = getenv("PARROT_GEMM2_W4_WN");
         env = e ? atoi(e) : 0;
     }
-    if (env == 2 || env == 4) return env;
-    return M <= G2M ? 4 : 2;
+    (void)M;
+    // measured (Llama-2-7B int4, 128- and 32-token prompts, uneven split-K): WN = 2 3.97 / 3.80 ms, WN = 4 4.77 / 4.33 ms - the wide
+    // shape does not pay; it stays selectable for A/B
+    return env == 4 ? 4 : 2;
 }
 
 int gemm2_w4_ksplit(int M, int N, int K, const W4Plan& plan) {
