@@ -205,6 +205,29 @@ def test_w4_gemm_matches_oracle_and_the_gemv(N, K, group, M):
     assert_bf16_close(out, ref.float(), ulps=1, atol=3e-3, what="w4_gemm vs gemv")
 
 
+@pytest.mark.parametrize("group,epi", [(128, EPI_SWIGLU), (64, EPI_RESIDUAL), (-1, EPI_GELU), (64, EPI_SWIGLU)])
+def test_w4_gemm_lds_dma_kernel_unsplit_launch_and_single_step_groups(group, epi):
+    """gemm2_w4_kernel without split-K (>= 192 tiles: the in-kernel epilogues, the two-pass SwiGLU with the gate kept in
+    registers), groups of one K-step (64), of two (128) and per-channel; last row tile ragged."""
+    M, N, K = 1500, 2048, 256
+    g = gen(37)
+    x, res = torch.randn(M, K, generator=g).to(BF), torch.randn(M, N, generator=g).to(BF)
+    bias = None if epi == EPI_SWIGLU else (torch.randn(N, generator=g) * 0.1).to(BF)
+    qw, s, z, tc, Wd = make_w4(N, K, group, 38)
+    qw2, s2, z2, _, Wd2 = make_w4(N, K, group, 39)
+    lin, lin2 = w4_module(qw, s, z, N, K, group, bias), w4_module(qw2, s2, z2, N, K, group)
+    out = torch.full((M + 1, N), 7.0, dtype=BF, device=DEV)
+    lin.hip_linear(x.to(DEV), out[:M], epilogue=epi, residual=res.to(DEV) if epi == EPI_RESIDUAL else None,
+                   partner=lin2 if epi == EPI_SWIGLU else None)
+    want = expected_epilogue(x.double() @ Wd.t(), x.double() @ Wd2.t(), bias, res, epi)
+    # every epilogue here applies a function to the Linear's result AFTER its rounding to bf16 (a reference rounding point): where the
+    # fp32 sum sits on a rounding tie, one ulp of that intermediate (2^-8 |v|, |v| <~ 2) moves the output by up to 8e-3 - with 3 M
+    # outputs a handful do
+    assert_bf16_close(out[:M], want, ulps=1, atol=8e-3, what=f"w4 gemm2 unsplit g={group} epi {epi}")
+    assert float((out[:M].cpu().double() - want).abs().mean()) < 2e-3
+    assert torch.all(out[M] == 7.0), "wrote past the last row"
+
+
 @pytest.mark.parametrize("epi", [EPI_RESIDUAL, EPI_GELU, EPI_SWIGLU])
 @pytest.mark.parametrize("kind", ["w4", "bf16"])
 def test_gemm_epilogues(epi, kind):
