@@ -105,6 +105,12 @@ int parrot_w4c_gemv(const void* packed, const void* packed2, const void* code16_
                     int epilogue, const parrot_norm_t* norm, void* stream);
 int parrot_w4c_dequant(const void* packed, const void* code16_f32, void* out, int ldo, int N, int K, int block,
                        void* stream);
+/* any M (prefill) on the matrix cores with the GEMV's numerics (bf16 codebook, absmax applied per block): the codebook variant of
+ * parrot_w4_gemm's kernel (packed weights by LDS-DMA, fragments looked up in registers in front of the MFMAs).  M <= 8 forwards
+ * to the GEMV; M > 8: norm == NULL, K % 64 == 0, workspace = parrot_gemm_workspace_floats(M, N, K, block, epilogue) floats.    */
+int parrot_w4c_gemm(const void* packed, const void* packed2, const void* code16_bf16, const void* x, int ldx, int M,
+                    const void* bias, const void* residual, int ldr, void* out, int ldo, int N, int K, int block,
+                    int epilogue, const parrot_norm_t* norm, void* workspace, void* stream);
 
 /* ---- dense bf16 Linear (torch.nn.Linear on the bf16 path, lit_gpt/model.py:29,188,190,281-295)
  * W is (N, K) row-major bf16.                                                    */

@@ -72,6 +72,7 @@ SIGNATURES = {
     "parrot_w4_repack": (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _i, _vp]),
     "parrot_w4_gemv": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _np, _vp]),
     "parrot_w4c_gemv": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _np, _vp]),
+    "parrot_w4c_gemm": (_i, [_vp, _vp, _vp, _vp, _i, _i, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _np, _vp, _vp]),
     "parrot_w4c_dequant": (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     "parrot_gemm_workspace_floats": (_i64, [_i, _i, _i, _i, _i]),
     "parrot_w4_gemm": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _np, _vp, _vp]),

@@ -365,7 +365,7 @@ int gemm2_w4_ksplit(int M, int N, int K, const W4Plan& plan);
 int64_t gemm2_w4_xs_floats(int M, const W4Plan& plan);
 int gemm2_w4_launch(const void* Wq, const void* Wq2, const void* x, int ldx, int M, const void* bias, const void* residual, int ldr,
                     void* out, int ldo, int N, int K, int epilogue, float* workspace, const W4Plan& plan, hipStream_t st, int* ksplit_out,
-                    float** part_out, float** part2_out);
+                    float** part_out, float** part2_out, const void* code);
 static bool gemm2_takes(int K, int ldx, int epilogue, const void* W, const void* x) {
     return gemm2_enabled() && epilogue != PARROT_EPI_SWIGLU && K % 64 == 0 && ldx % 8 == 0 && aligned16(W) && aligned16(x);
 }
@@ -446,7 +446,7 @@ int parrot_w4_gemm(const void* packed, const void* packed2, const void* x, int l
         int ks = 1;
         float *part = nullptr, *part2 = nullptr;
         rc = gemm2_w4_launch(packed, packed2, x, ldx, M, bias, residual, ldr, out, ldo, N, K, epilogue, (float*)workspace, plan, st, &ks,
-                             &part, &part2);
+                             &part, &part2, nullptr);
         if (rc != PARROT_OK || ks == 1) return rc;
         const int64_t mn = (int64_t)M * N;
         return launch(K_GEMM_SPLITK, gemm_splitk_epilogue_kernel, dim3((unsigned)((mn + 255) / 256)), dim3(256), 0, st, (const float*)part,
@@ -460,6 +460,34 @@ int parrot_w4_gemm(const void* packed, const void* packed2, const void* x, int l
     // the split-K partials follow the activation sums in the workspace
     return gemm_launch<true>(K_W4_GEMM, packed, packed2, x, ldx, M, bias, residual, ldr, out, ldo, N, K, epilogue, (const float*)workspace,
                              (float*)workspace + n, plan, plan.Gs, st);
+}
+
+// NF4 / FP4 (bitsandbytes 4-bit) prompt rows on the matrix cores: the codebook variant of the int4 LDS-DMA kernel.  Needs
+// K % 64 == 0 and blocks of 64; `workspace` = parrot_gemm_workspace_floats(M, N, K, block, epilogue) floats (split-K partials).
+int parrot_w4c_gemm(const void* packed, const void* packed2, const void* code16_bf16, const void* x, int ldx, int M, const void* bias,
+                    const void* residual, int ldr, void* out, int ldo, int N, int K, int block, int epilogue,
+                    const parrot_norm_t* norm, void* workspace, void* stream) {
+    if (M <= 8)
+        return parrot_w4c_gemv(packed, packed2, code16_bf16, x, ldx, M, bias, residual, ldr, out, ldo, N, K, block, epilogue, norm, stream);
+    int rc = check_linear_args("w4c_gemm", packed, packed2, x, ldx, M, residual, ldr, out, ldo, N, K, epilogue);
+    if (rc != PARROT_OK) return rc;
+    PARROT_REQUIRE(code16_bf16 != nullptr, "w4c_gemm: codebook pointer is null");
+    PARROT_UNSUPPORTED(norm == nullptr || norm->kind == 0, "w4c_gemm: apply the norm to the rows first (parrot_rmsnorm / parrot_layernorm)");
+    PARROT_REQUIRE(workspace != nullptr, "w4c_gemm: workspace of parrot_gemm_workspace_floats(M, N, K, block, epilogue) floats required");
+    PARROT_UNSUPPORTED(!(epilogue == PARROT_EPI_SWIGLU && bias), "w4c_gemm: SWIGLU epilogue takes no bias");
+    W4Plan plan;
+    rc = w4_make_plan(N, K, block, &plan);
+    if (rc != PARROT_OK) return rc;
+    PARROT_UNSUPPORTED(gemm2_w4_takes(plan, K) && ldx % 8 == 0, "w4c_gemm: needs K %% 64 == 0, blocks that are multiples of 64 and 16-byte rows (K=%d block=%d)", K, block);
+    hipStream_t st = (hipStream_t)stream;
+    int ks = 1;
+    float *part = nullptr, *part2 = nullptr;
+    rc = gemm2_w4_launch(packed, packed2, x, ldx, M, bias, residual, ldr, out, ldo, N, K, epilogue, (float*)workspace, plan, st, &ks, &part,
+                         &part2, code16_bf16);
+    if (rc != PARROT_OK || ks == 1) return rc;
+    const int64_t mn = (int64_t)M * N;
+    return launch(K_GEMM_SPLITK, gemm_splitk_epilogue_kernel, dim3((unsigned)((mn + 255) / 256)), dim3(256), 0, st, (const float*)part,
+                  (const float*)part2, ks, M, N, (const bf16_t*)bias, (const bf16_t*)residual, ldr, (bf16_t*)out, ldo, epilogue);
 }
 
 }  // extern "C"

@@ -290,11 +290,41 @@ __device__ __forceinline__ void glds4_asm(const void* gsrc, const void* lds_dst_
 //                    4 -> 128 x 256 tile, 8 waves, ring of 6 stages, one workgroup per CU (147 KB): for launches with ONE m-tile
 //                         (prompts up to 128 rows), which are bound by the weight stream - a third of every stage comes from HBM
 //                         instead of a fifth, and five stages are in flight instead of two.
-template <bool SPLIT, bool SWI, int WN>
+// CB = codebook weights (bitsandbytes NF4 / FP4, parrot_w4c_gemm): the nibbles index a 16-entry bf16 codebook kept in LDS as one
+// private column per lane at LDS offset 0 (the GEMV's scheme: w4_plan.h w4c_slice_lookup), the group word is the block's fp32
+// absmax and the fold is total += absmax * acc (groups of 64 = one K-step): the numerics of the decode kernel.
+__device__ __forceinline__ void w4c_dword_lookup(uint32_t dw, uint32_t cb_addr, uint32_t (&o)[4]) {
+    uint32_t a0 = cb_addr, a1 = cb_addr, lo[4], hi[4];
+    const uint32_t lo4 = dw, hi4 = dw >> 4;
+#define G2_CB_READ(R, A, SRC, SEL)                                                                                         \
+    asm volatile("v_and_b32_sdwa %1, 15, %2 dst_sel:BYTE_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD src1_sel:" SEL "\n\t"  \
+                 "ds_read_u16 %0, %1"                                                                                      \
+                 : "=&v"(R), "+v"(A)                                                                                       \
+                 : "v"(SRC)                                                                                                \
+                 : "memory")
+    G2_CB_READ(lo[0], a0, lo4, "BYTE_0");
+    G2_CB_READ(hi[0], a1, lo4, "BYTE_2");
+    G2_CB_READ(lo[1], a0, hi4, "BYTE_0");
+    G2_CB_READ(hi[1], a1, hi4, "BYTE_2");
+    G2_CB_READ(lo[2], a0, lo4, "BYTE_1");
+    G2_CB_READ(hi[2], a1, lo4, "BYTE_3");
+    G2_CB_READ(lo[3], a0, hi4, "BYTE_1");
+    G2_CB_READ(hi[3], a1, hi4, "BYTE_3");
+#undef G2_CB_READ
+    asm volatile("s_waitcnt lgkmcnt(0)"
+                 : "+v"(lo[0]), "+v"(lo[1]), "+v"(lo[2]), "+v"(lo[3]), "+v"(hi[0]), "+v"(hi[1]), "+v"(hi[2]), "+v"(hi[3])
+                 :
+                 : "memory");
+#pragma unroll
+    for (int q = 0; q < 4; ++q) o[q] = lo[q] | (hi[q] << 16);
+}
+
+template <bool SPLIT, bool SWI, int WN, bool CB>
 __global__ void __launch_bounds__(WN * 128) __attribute__((amdgpu_waves_per_eu(2, 2)))
 gemm2_w4_kernel(const bf16_t* __restrict__ A, int lda, int M, const uint4* __restrict__ Wq, const uint4* __restrict__ Wq2, int N,
                 int K, const float* __restrict__ xsT, int Mpad, const bf16_t* __restrict__ bias, const bf16_t* residual, int ldr,
-                bf16_t* out, int ldo, int epi, W4Plan plan, int ksplit, float* __restrict__ part, float* __restrict__ part2, G2Map mp) {
+                bf16_t* out, int ldo, int epi, W4Plan plan, int ksplit, float* __restrict__ part, float* __restrict__ part2, G2Map mp,
+                const uint32_t* __restrict__ code) {
     constexpr int TN = WN * 64;                      // tile columns
     constexpr int NWAVES = 2 * WN;
     constexpr int W4_NBUF = WN == 2 ? 3 : 6;
@@ -302,9 +332,16 @@ gemm2_w4_kernel(const bf16_t* __restrict__ A, int lda, int M, const uint4* __res
     constexpr int W4_META16 = 32 + TN / 4;           // 128 activation sums + TN {scale, zero} words
     constexpr int A_PER_WAVE = 16 / NWAVES;          // 1-KB LDS-DMA pieces of the A tile per wave
     constexpr int TILE_LOADS = A_PER_WAVE + 1;       // LDS-DMA loads per wave and K-step
-    __shared__ __attribute__((aligned(1024))) uint4 smem[W4_NBUF * W4_STAGE16 + 2 * W4_META16];
+    constexpr int CB16 = CB ? 256 : 0;               // codebook columns (16 entries x 64 lanes x 4 B) in front of the ring
+    __shared__ __attribute__((aligned(4096))) uint4 smem_all[CB16 + W4_NBUF * W4_STAGE16 + 2 * W4_META16];
+    uint4* const smem = smem_all + CB16;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WN, wn = wave % WN;
+    if constexpr (CB) {  // (visible after the barrier that opens the first pass)
+        if (((uint32_t)(uintptr_t)smem_all & 0xFFFFu) != 0) __builtin_trap();  // the lookups write the nibble into byte 1 of an address based at 0
+        for (int e = wave; e < 16; e += NWAVES) reinterpret_cast<uint32_t*>(smem_all)[e * 64 + lane] = code[e];
+    }
+    const uint32_t cb_addr = lane * 4;
     int mt_, nt_, z_;
     g2_tile_of(mp, blockIdx.x, mt_, nt_, z_);
     const int m0 = mt_ * G2M, n0 = nt_ * TN, zsplit = z_;
@@ -370,7 +407,7 @@ gemm2_w4_kernel(const bf16_t* __restrict__ A, int lda, int M, const uint4* __res
         auto issue_meta = [&](int g) {  // one 4-byte LDS-DMA per wave
             uint4* mb = meta + (g & 1) * W4_META16;
             if (wave < 2) {
-                glds4_asm(xs_src + (int64_t)g * Mpad, reinterpret_cast<float*>(mb) + wave * 64);
+                if constexpr (!CB) glds4_asm(xs_src + (int64_t)g * Mpad, reinterpret_cast<float*>(mb) + wave * 64);
             } else if (wave < 2 + WN) {
                 int gs = 0;
                 while (gs + 1 < plan.nslabs && 2 * g * Gt >= plan.slab[gs + 1].slice0) ++gs;
@@ -421,8 +458,12 @@ gemm2_w4_kernel(const bf16_t* __restrict__ A, int lda, int M, const uint4* __res
                 for (int i = 0; i < 2; ++i) {
                     af[i] = __builtin_bit_cast(bf16x8_t, sa[a_row[i] * 8 + (slot ^ ((a_row[i] >> 1) & 7))]);
                     uint32_t o[4];
+                    if constexpr (CB) {
+                        w4c_dword_lookup(bw[i][ks], cb_addr, o);
+                    } else {
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) o[q] = ((bw[i][ks] >> (4 * q)) & 0x000F000Fu) | 0x43004300u;
+                        for (int q = 0; q < 4; ++q) o[q] = ((bw[i][ks] >> (4 * q)) & 0x000F000Fu) | 0x43004300u;
+                    }
                     bfr[i] = __builtin_bit_cast(bf16x8_t, make_uint4(o[0], o[1], o[2], o[3]));
                 }
 #pragma unroll
@@ -435,21 +476,27 @@ gemm2_w4_kernel(const bf16_t* __restrict__ A, int lda, int M, const uint4* __res
                 const float* xs_l = reinterpret_cast<const float*>(mb);
                 const uint32_t* mt_l = reinterpret_cast<const uint32_t*>(mb + 32);
                 float4 xs4[2][4];
+                if constexpr (!CB) {
 #pragma unroll
-                for (int i = 0; i < 2; ++i)
+                    for (int i = 0; i < 2; ++i)
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) xs4[i][q] = *reinterpret_cast<const float4*>(xs_l + wm * 64 + i * 32 + 8 * q + 4 * lh);
+                        for (int q = 0; q < 4; ++q) xs4[i][q] = *reinterpret_cast<const float4*>(xs_l + wm * 64 + i * 32 + 8 * q + 4 * lh);
+                }
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
                     const uint32_t mt = mt_l[c_row[j]];
-                    const float sc = bflo(mt), zz = 128.0f + bfhi(mt);
+                    const float sc = CB ? __uint_as_float(mt) : bflo(mt), zz = CB ? 0.f : 128.0f + bfhi(mt);
 #pragma unroll
                     for (int i = 0; i < 2; ++i)
 #pragma unroll
                         for (int r = 0; r < 16; ++r) {
-                            const float4 x4 = xs4[i][r >> 2];
-                            const float xs = (r & 3) == 0 ? x4.x : ((r & 3) == 1 ? x4.y : ((r & 3) == 2 ? x4.z : x4.w));
-                            total[i][j][r] += sc * (acc[i][j][r] - zz * xs);
+                            if constexpr (CB) {
+                                total[i][j][r] += sc * acc[i][j][r];
+                            } else {
+                                const float4 x4 = xs4[i][r >> 2];
+                                const float xs = (r & 3) == 0 ? x4.x : ((r & 3) == 1 ? x4.y : ((r & 3) == 2 ? x4.z : x4.w));
+                                total[i][j][r] += sc * (acc[i][j][r] - zz * xs);
+                            }
                             acc[i][j][r] = 0.f;
                         }
                 }
@@ -542,10 +589,12 @@ int64_t gemm2_w4_xs_floats(int M, const W4Plan& plan) { return (int64_t)((M + G2
 
 int gemm2_w4_launch(const void* Wq, const void* Wq2, const void* x, int ldx, int M, const void* bias, const void* residual, int ldr,
                     void* out, int ldo, int N, int K, int epilogue, float* workspace, const W4Plan& plan, hipStream_t st, int* ksplit_out,
-                    float** part_out, float** part2_out) {
+                    float** part_out, float** part2_out, const void* code) {
     const int Mpad = (M + G2M - 1) / G2M * G2M;
-    const int64_t nxs = (int64_t)Mpad * plan.ngroups;
-    int rc = launch(K_GEMM_XSUM, gemm2_xsum_kernel, dim3((unsigned)((nxs + 255) / 256)), dim3(256), 0, st, (const bf16_t*)x, ldx, M, Mpad, K,
+    const int64_t nxs = code ? 0 : (int64_t)Mpad * plan.ngroups;  // codebook weights need no activation sums
+    int rc = PARROT_OK;
+    if (!code)
+        rc = launch(K_GEMM_XSUM, gemm2_xsum_kernel, dim3((unsigned)((nxs + 255) / 256)), dim3(256), 0, st, (const bf16_t*)x, ldx, M, Mpad, K,
                     plan.Gs * 32, plan.ngroups, workspace);
     if (rc != PARROT_OK) return rc;
     const int ks = gemm2_w4_ksplit(M, N, K, plan);
@@ -565,11 +614,20 @@ int gemm2_w4_launch(const void* Wq, const void* Wq2, const void* x, int ldx, int
     mp.GM = g2_largest_divisor_le(mp.MT, 8);
     mp.GN = mp.xcd_ok ? g2_largest_divisor_le(mp.NT / 8, resident_per_xcd / mp.GM > 0 ? resident_per_xcd / mp.GM : 1) : 1;
     const dim3 grid((unsigned)total);
-#define PARROT_G2W_GO(SPLITV, SWIV, WNV)                                                                                            \
-    return launch(K_W4_GEMM, gemm2_w4_kernel<SPLITV, SWIV, WNV>, grid, dim3(WNV * 128), 0, st, (const bf16_t*)x, ldx, M, (const uint4*)Wq, \
-                  (const uint4*)Wq2, N, K, (const float*)workspace, Mpad, (const bf16_t*)bias, (const bf16_t*)residual, ldr, (bf16_t*)out, \
-                  ldo, epilogue, plan, ks, part, part2, mp)
+#define PARROT_G2W_GO_CB(SPLITV, SWIV, WNV, CBV)                                                                                    \
+    return launch(CBV ? K_W4C_GEMM : K_W4_GEMM, gemm2_w4_kernel<SPLITV, SWIV, WNV, CBV>, grid, dim3(WNV * 128), 0, st, (const bf16_t*)x, ldx, \
+                  M, (const uint4*)Wq, (const uint4*)Wq2, N, K, (const float*)workspace, Mpad, (const bf16_t*)bias, (const bf16_t*)residual, \
+                  ldr, (bf16_t*)out, ldo, epilogue, plan, ks, part, part2, mp, (const uint32_t*)code)
+#define PARROT_G2W_GO(SPLITV, SWIV, WNV) PARROT_G2W_GO_CB(SPLITV, SWIV, WNV, false)
     const bool swi = epilogue == PARROT_EPI_SWIGLU;
+    if (code) {  // codebook weights: the 128 x 128 shape only
+        if (ks > 1) {
+            if (swi) PARROT_G2W_GO_CB(true, true, 2, true);
+            PARROT_G2W_GO_CB(true, false, 2, true);
+        }
+        if (swi) PARROT_G2W_GO_CB(false, true, 2, true);
+        PARROT_G2W_GO_CB(false, false, 2, true);
+    }
     if (wn == 4) {
         if (ks > 1) {
             if (swi) PARROT_G2W_GO(true, true, 4);
@@ -585,6 +643,7 @@ int gemm2_w4_launch(const void* Wq, const void* Wq2, const void* x, int ldx, int
     if (swi) PARROT_G2W_GO(false, true, 2);
     PARROT_G2W_GO(false, false, 2);
 #undef PARROT_G2W_GO
+#undef PARROT_G2W_GO_CB
 }
 
 }  // namespace parrot

@@ -74,6 +74,7 @@ enum KernelId : int {
     K_W4C_DEQUANT,
     K_GEMM_XSUM,
     K_GEMM_SPLITK,
+    K_W4C_GEMM,
     K_COUNT
 };
 

@@ -157,23 +157,35 @@ def w4c_dequant(packed: torch.Tensor, code_f32: torch.Tensor, N: int, K: int, bl
     return out
 
 
+W4C_PREFILL_FUSED = True  # prompts: the codebook GEMM (GEMV numerics); False = dequantise + dense GEMM (bitsandbytes' order)
+
+
 def w4c_linear(packed: torch.Tensor, code_words: torch.Tensor, code_f32: torch.Tensor, N: int, K: int, block: int, x: torch.Tensor,
                out: torch.Tensor, *, bias=None, epilogue=EPI_NONE, residual=None, packed2=None, norm: Optional[Norm] = None) -> torch.Tensor:
     """Linear over 4-bit codebook weights.  Up to GEMV_MAX_ROWS rows: the fused dequant-into-GEMV kernel.  More rows
-    (prefill): dequantise to bf16 and multiply on the matrix cores - the order of operations of bitsandbytes' MatMul4Bit."""
+    (prefill): the codebook GEMM on the matrix cores (same numerics as the GEMV), or - W4C_PREFILL_FUSED = False, K not a multiple
+    of 64 - dequantise to bf16 and multiply, the order of operations of bitsandbytes' MatMul4Bit."""
     _rows(x, "w4c_linear"), _rows(out, "w4c_linear")
     M = x.shape[0]
     if x.shape[1] != K or out.shape[1] != N:
         raise ParrotHipError(f"w4c_linear: x {tuple(x.shape)} / out {tuple(out.shape)} do not match N={N} K={K}")
     if code_words.dtype != torch.int32 or code_words.numel() != 16:
         raise ParrotHipError("w4c_linear: the bf16 codebook is passed as 16 int32 words")
+    x, norm = _prenorm(x, norm)
     if M > GEMV_MAX_ROWS:
+        lib = _hip.load()
+        if K % 64 == 0 and W4C_PREFILL_FUSED:
+            ws = torch.empty((max(1, lib.parrot_gemm_workspace_floats(M, N, K, block, epilogue)),), dtype=torch.float32, device=x.device)
+            check(lib.parrot_w4c_gemm(ptr(packed), ptr(packed2), ptr(code_words), ptr(x), x.stride(0), M, ptr(_opt_vec(bias, N, "bias")),
+                                      ptr(residual), residual.stride(0) if residual is not None else 0, ptr(out), out.stride(0), N, K,
+                                      block, epilogue, None, ptr(ws), stream()), "parrot_w4c_gemm")
+            return out
+        # bitsandbytes' own order of operations: dequantise to bf16, then a dense GEMM
         dense = w4c_dequant(packed, code_f32, N, K, block, torch.empty((N, K), dtype=torch.bfloat16, device=x.device))
         dense2 = None
         if packed2 is not None:
             dense2 = w4c_dequant(packed2, code_f32, N, K, block, torch.empty((N, K), dtype=torch.bfloat16, device=x.device))
-        return bf16_linear(dense, x, out, bias=bias, epilogue=epilogue, residual=residual, weight2=dense2, norm=norm)
-    x, norm = _prenorm(x, norm)
+        return bf16_linear(dense, x, out, bias=bias, epilogue=epilogue, residual=residual, weight2=dense2)
     check(_hip.load().parrot_w4c_gemv(ptr(packed), ptr(packed2), ptr(code_words), ptr(x), x.stride(0), M,
                                       ptr(_opt_vec(bias, N, "bias")), ptr(residual), residual.stride(0) if residual is not None else 0,
                                       ptr(out), out.stride(0), N, K, block, epilogue, _norm_arg(norm, K), stream()), "parrot_w4c_gemv")
