@@ -1,0 +1,163 @@
+"""BASELINE.json's full-size configurations on the GPU, checked through properties that need no full-size oracle run:
+
+* prefill == decode: the logits after a T-token prompt computed by the prompt path (MFMA GEMMs over T rows, attention over all
+  rows) against the same T tokens fed one at a time through the decode path (weight-streaming GEMVs, fused attention) - two
+  independent kernel families, each held to the CPU oracle on small shapes elsewhere, must agree at full size;
+* hipGraph replay == eager launches, token for token, and a second run from the same prompt repeats the first bit for bit;
+* sampled output rows of a full-size Linear (lm_head: 32000 x 4096 int4) against float64 arithmetic on the dequantised rows;
+* the W4K repack of a full-size matrix inverts exactly.
+Synthetic random-init weights of the named architectures (there are no checkpoints offline), as in bench.py.
+"""
+import pytest
+import torch
+
+from helpers import assert_bf16_close, rbf
+
+pytestmark = pytest.mark.gpu
+
+from lit_parrot_amd import ops  # noqa: E402
+from lit_parrot_amd.config import Config  # noqa: E402
+from lit_parrot_amd.generate import base as gb  # noqa: E402
+from lit_parrot_amd.quantize.gptq import ColBlockQuantizedLinear  # noqa: E402
+from lit_parrot_amd.synth import build_synthetic_model, synthetic_prompt  # noqa: E402
+
+DEV = torch.device("cuda", 0)
+BF = torch.bfloat16
+
+
+@pytest.fixture(scope="module")
+def llama7b_int4():
+    model = build_synthetic_model(Config.from_name("Llama-2-7b-hf"), "gptq.int4-g128", seed=1234, device=DEV)
+    yield model
+    del model
+    torch.cuda.empty_cache()
+
+
+def _decode_path_logits(model, prompt, S):
+    """Feed the prompt one token at a time through the single-row step (no graph): logits after the last prompt token."""
+    sess = gb.DecodeSession(model, S, S, greedy=False, use_graph=False)
+    sess.tokens[: prompt.numel()].copy_(prompt)
+    sess.pos.zero_()
+    logits = None
+    for t in range(prompt.numel()):
+        sess.pos.fill_(t)
+        logits = sess.step().clone()
+    return logits
+
+
+@torch.no_grad()
+def test_llama2_7b_int4_prefill_equals_decode_and_replay_is_deterministic(llama7b_int4):
+    model, cfg = llama7b_int4, llama7b_int4.config
+    T, S, new = 48, 96, 24
+    prompt = synthetic_prompt(cfg, T, seed=99).to(DEV)
+    # (1) prompt path vs token-by-token decode path
+    model.reset_cache()
+    sess = gb.DecodeSession(model, S, S, greedy=True)
+    lp = sess.prefill(prompt).float().view(-1).clone()
+    model.reset_cache()
+    ld = _decode_path_logits(model, prompt, S).float().view(-1)
+    # Both paths round to bf16 at the same ~160 points but sum in different orders, and a random-init network passes such one-ulp
+    # flips on: measured relative rms of the difference 0.5 % with 1 layer, 0.9 % with 2, 2.2 % with 8, 5 % with 32 (the same with
+    # either GEMM generation: tools/debug/prefill_vs_decode.py).  Full depth is therefore held to a statistical bound; the
+    # full-WIDTH kernels are held to the tight one on a 2-layer model below.
+    scale = max(1.0, float(ld.abs().max()))
+    rel_rms = float((lp - ld).pow(2).mean().sqrt() / ld.pow(2).mean().sqrt())
+    assert rel_rms <= 0.10, rel_rms
+    assert float(ld[lp.argmax()]) >= float(ld.max()) - 0.1 * scale  # the prompt path's arg-max is (noise-aware) the decode path's
+    # (2) graph replay == eager steps, and a second run repeats the first
+    runs = []
+    for use_graph in (True, False, True):
+        model.reset_cache()
+        s = gb.DecodeSession(model, S, S, greedy=True, use_graph=use_graph)
+        logits = s.prefill(prompt)
+        ops.argmax_advance(logits, s.tokens, s.pos)
+        s.capture()
+        for _ in range(new):
+            s.step()
+        torch.cuda.synchronize()
+        assert int(s.pos.item()) == T + new
+        runs.append(s.tokens[: T + new + 1].clone())
+    assert torch.equal(runs[0], runs[1]), "hipGraph replay and eager launches disagree"
+    assert torch.equal(runs[0], runs[2]), "the same prompt gave different tokens the second time"
+    assert torch.equal(runs[0][:T], prompt)
+    model.reset_cache()
+
+
+@torch.no_grad()
+@pytest.mark.parametrize("mode", ["gptq.int4-g128", "bnb.nf4", None])
+def test_llama2_7b_width_two_layers_prefill_equals_decode(mode):
+    """Full-width Linears (4096 / 11008 / 32000, every launch shape of the 7B step and prompt), two layers deep: the prompt path and
+    the decode path agree within the int4 bound of north_star plus one bf16 ulp of the logits."""
+    from lit_parrot_amd.config import name_to_config
+
+    cfg = Config(**{**name_to_config["Llama-2-7b-hf"], "n_layer": 2})
+    model = build_synthetic_model(cfg, mode, seed=1234, device=DEV)
+    T, S = 130, 160  # two row tiles of the prompt GEMMs, the second ragged
+    prompt = synthetic_prompt(cfg, T, seed=3).to(DEV)
+    sess = gb.DecodeSession(model, S, S, greedy=False, use_graph=False)
+    lp = sess.prefill(prompt).float().view(-1).clone()
+    model.reset_cache()
+    ld = _decode_path_logits(model, prompt, S).float().view(-1)
+    scale = max(1.0, float(ld.abs().max()))
+    assert float((lp - ld).abs().max()) <= (1e-2 + 2 ** -7) * scale, float((lp - ld).abs().max())
+    assert float((lp - ld).abs().mean()) <= 3e-3 * scale
+    assert float(ld[lp.argmax()]) >= float(ld.max()) - 2 ** -6 * scale
+    del model, sess
+    torch.cuda.empty_cache()
+
+
+@torch.no_grad()
+def test_llama2_7b_int4_lm_head_rows_against_float64(llama7b_int4):
+    """64 sampled rows of the largest launch of the step (lm_head: 32000 x 4096, 70 MB of int4) and 64 of the SwiGLU pair."""
+    model = llama7b_int4
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(1, 4096, generator=g).to(BF)
+    head: ColBlockQuantizedLinear = model.lm_head
+    out = head(x.to(DEV)).float().cpu().view(-1)
+    rows = torch.randint(0, head.out_features, (64,), generator=g)
+    W = head.get_weight(torch.float32)[rows.to(DEV)].double().cpu()  # exact (q - z) * s of the sampled rows
+    want = rbf(x.double() @ W.t()).view(-1)
+    assert_bf16_close(out[rows].to(BF), want, ulps=1, atol=2e-3, what="lm_head rows")
+    mlp = model.transformer.h[7].mlp
+    h = torch.empty((1, mlp.fc_1.out_features), dtype=BF, device=DEV)
+    from lit_parrot_amd._hip import EPI_SWIGLU
+
+    mlp.fc_1.hip_linear(x.to(DEV), h, epilogue=EPI_SWIGLU, partner=mlp.fc_2)
+    rows = torch.randint(0, mlp.fc_1.out_features, (64,), generator=g)
+    W1 = mlp.fc_1.get_weight(torch.float32)[rows.to(DEV)].double().cpu()
+    W2 = mlp.fc_2.get_weight(torch.float32)[rows.to(DEV)].double().cpu()
+    want = rbf(torch.nn.functional.silu(rbf(x.double() @ W1.t()))) * rbf(x.double() @ W2.t())
+    assert_bf16_close(h.cpu().view(-1)[rows], want.view(-1), ulps=1, atol=2e-3, what="SwiGLU rows")
+
+
+@torch.no_grad()
+def test_full_size_repack_round_trip(llama7b_int4):
+    head: ColBlockQuantizedLinear = llama7b_int4.lm_head
+    N, K, G = head.out_features, head.in_features, head.tile_cols
+    qw2 = torch.zeros_like(head.quant_weight)
+    s2, z2 = torch.zeros_like(head.scales), torch.zeros_like(head.zeros)
+    ops.w4_repack(qw2, s2, z2, N, K, G, head.packed(), 1)
+    assert torch.equal(qw2, head.quant_weight) and torch.equal(s2, head.scales) and torch.equal(z2, head.zeros)
+
+
+@torch.no_grad()
+def test_stablelm_3b_bf16_prefill_equals_decode():
+    """BASELINE configs[1] at full size: 512-token prompt on the LDS-DMA GEMMs vs the same tokens through the decode kernels
+    (the last 40 of them: the first 472 only fill the cache, which the prompt path wrote - so the two paths also share a cache)."""
+    cfg = Config.from_name("stablelm-base-alpha-3b")
+    model = build_synthetic_model(cfg, None, seed=1234, device=DEV)
+    T, S = 512, 768
+    prompt = synthetic_prompt(cfg, T, seed=7).to(DEV)
+    sess = gb.DecodeSession(model, S, S, greedy=False, use_graph=False)
+    lp = sess.prefill(prompt).float().view(-1).clone()
+    ld = None
+    for t in range(T - 40, T):  # re-run the tail of the prompt row by row on top of the cache the prompt path wrote
+        sess.pos.fill_(t)
+        ld = sess.step().clone()
+    ld = ld.float().view(-1)
+    scale = max(1.0, float(ld.abs().max()))
+    rel_rms = float((lp - ld).pow(2).mean().sqrt() / ld.pow(2).mean().sqrt())
+    assert rel_rms <= 0.05, rel_rms  # 16 layers of bf16 re-rounding in two summation orders (see the 7B test above)
+    assert float(ld[lp.argmax()]) >= float(ld.max()) - 0.1 * scale
+    del model, sess
+    torch.cuda.empty_cache()
