@@ -173,6 +173,15 @@ int parrot_attn_decode(const void* q, int M, const int32_t* pos, const void* k_c
                        const void* v_cache, int n_groups, int q_per_kv, int hs, int S, int nsplit,
                        void* workspace, void* y, int ldy, void* stream);
 
+/* Prompt rows on the matrix cores: y[m] = softmax(q[m] k^T / sqrt(hs), keys 0 .. *pos + m) v for the M rows of one prefill call
+ * (lit_gpt/model.py:256-275 with the causal mask of :126-128), flash-attention style (32 queries per wave, key blocks of 32,
+ * v_mfma_f32_32x32x16_bf16 for Q.K^T and P.V, P rounded to bf16).  Requires *pos + M <= S (no ring wrap inside the call).
+ * q: [M][n_head*hs] roped (parrot_qkv_rope_kvappend), caches as for parrot_attn_decode; vT_scratch: bf16,
+ * parrot_attn_prefill_scratch_elems(n_groups, hs, S) elements (the call's V rows transposed to [group][dim][slot]).            */
+int64_t parrot_attn_prefill_scratch_elems(int n_groups, int hs, int S);
+int parrot_attn_prefill(const void* q, int M, const int32_t* pos, const void* k_cache, const void* v_cache,
+                        void* vT_scratch, int n_groups, int q_per_kv, int hs, int S, void* y, int ldy, void* stream);
+
 /* Decode step (one new token) of CausalSelfAttention in ONE launch: q/k/v split + RoPE + KV append + attention over
  * slots 0..min(*pos, S-1) + cross-split combine (lit_gpt/model.py:208-247).  qkv: one row; y: [n_head*hs] bf16.
  * workspace as for parrot_attn_decode (M = 1); tickets: n_head zero-initialised uint32 (one per group and chunk of query heads; re-armed by the kernel). */

@@ -10,7 +10,7 @@ from pathlib import Path
 PKG_DIR = Path(__file__).resolve().parent
 CSRC = PKG_DIR / "csrc"
 LIB_PATH = PKG_DIR / "libparrot_hip.so"
-SOURCES = ["core.hip", "w4.hip", "dense.hip", "w8.hip", "norm.hip", "attn.hip", "misc.hip", "persist.hip", "gemm.hip", "gemm2.hip", "gptq.hip"]
+SOURCES = ["core.hip", "w4.hip", "dense.hip", "w8.hip", "norm.hip", "attn.hip", "attn_prefill.hip", "misc.hip", "persist.hip", "gemm.hip", "gemm2.hip", "gptq.hip"]
 ARCH = "gfx950"
 
 

@@ -88,6 +88,8 @@ SIGNATURES = {
     "parrot_attn_workspace_floats": (_i64, [_i, _i, _i, _i]),
     "parrot_attn_decode": (_i, [_vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _i, _vp]),
     "parrot_attn_fused_decode": (_i, [_vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "parrot_attn_prefill_scratch_elems": (_i64, [_i, _i, _i]),
+    "parrot_attn_prefill": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _i, _vp]),
     "parrot_attn_fused_decode_pf": (_i, [_vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp]),
     "parrot_pk_fill_w4": (_i, [C.POINTER(PkOp), _i, _i, _i]),
     "parrot_pk_step": (_i, [C.POINTER(PkState), _vp]),

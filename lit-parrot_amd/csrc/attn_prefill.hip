@@ -1,0 +1,186 @@
+// Causal attention over the T prompt rows on the matrix cores (reference lit_gpt/model.py:256-275 scaled_dot_product_attention
+// with the tril mask of :126-128, for the rows of one prefill call; q is already split + roped, K / V are in the cache).
+//
+// One wave owns 32 consecutive query rows of one head and walks the key blocks of 32 up to its diagonal (flash attention:
+// running max / sum, no T x T matrix).  Everything is arranged so that a LANE belongs to ONE query:
+//   S^T = K_blk . Q^T        v_mfma_f32_32x32x16_bf16 with A = K rows (keys x dims, as they lie in the cache), B = the wave's Q rows:
+//                            lane l holds the scores of query l & 31 for 16 of the block's 32 keys (the other 16 sit in lane l ^ 32);
+//   softmax                  max / sum over the lane's 16 registers + one exchange with lane l ^ 32; the rescale factor is per lane;
+//   O^T += V^T_blk . P^T     A = V^T (dims x keys), B = P^T straight from the score registers (rounded to bf16): the MFMA's K index
+//                            may be any permutation as long as A and B agree, so registers 8 ks .. 8 ks + 7 of a lane ARE its B
+//                            fragment of step ks, and A takes the matching keys: two runs of four consecutive keys per lane.
+// V^T needs the keys contiguous per dim: a small pre-pass transposes the call's V rows into a scratch [group][dim][slot]
+// (zero beyond the last key, so that masked columns multiply finite numbers).  Requires *pos + M <= S (no ring wrap inside the
+// call): the prompt of generate().  P is rounded to bf16 before P.V (torch's flash kernels do the same; the decode kernels keep
+// P in fp32): results agree with the multi-row decode path to bf16 rounding.
+#include "parrot_common.h"
+
+namespace parrot {
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8_t;
+typedef __attribute__((ext_vector_type(16))) float f32x16_t;
+
+// vT[g][d][s] = V[g][s][d] for s < n_keys, 0 for n_keys <= s < Spad.  One thread per (g, s, 8 dims).
+__global__ void __launch_bounds__(256)
+attn_vt_kernel(const bf16_t* __restrict__ v_cache, const int32_t* __restrict__ pos_ptr, int M, int n_groups, int hs, int S, int Spad,
+               bf16_t* __restrict__ vT) {
+    const int n_keys = min(pos_ptr[0] + M, S);
+    const int n_fill = min((n_keys + 31) & ~31, Spad);
+    const int d8 = hs >> 3;
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int s = (int)(t % Spad);
+    const int c = (int)((t / Spad) % d8);
+    const int g = (int)(t / ((int64_t)Spad * d8));
+    if (g >= n_groups || s >= n_fill) return;
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (s < n_keys) v = *reinterpret_cast<const uint4*>(v_cache + ((int64_t)g * S + s) * hs + c * 8);
+    const uint32_t dw[4] = {v.x, v.y, v.z, v.w};
+    bf16_t* dst = vT + ((int64_t)g * hs + c * 8) * Spad + s;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        dst[(int64_t)(2 * i) * Spad] = (bf16_t)(dw[i] & 0xffffu);
+        dst[(int64_t)(2 * i + 1) * Spad] = (bf16_t)(dw[i] >> 16);
+    }
+}
+
+template <int HS>
+__global__ void __launch_bounds__(256)
+attn_prefill_kernel(const bf16_t* __restrict__ q, int ldq, int M, const int32_t* __restrict__ pos_ptr, const bf16_t* __restrict__ k_cache,
+                    const bf16_t* __restrict__ vT, int n_groups, int q_per_kv, int S, int Spad, bf16_t* __restrict__ y, int ldy) {
+    constexpr int KS = HS / 16;  // MFMA k-steps of Q.K^T
+    constexpr int DT = HS / 32;  // 32-dim tiles of the output
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lr = lane & 31, lh = lane >> 5;
+    const int h = blockIdx.y, g = h / q_per_kv;
+    // heavy (late) query blocks first: the grid's x index counts down
+    const int qb = ((int)gridDim.x - 1 - (int)blockIdx.x) * 4 + wave;
+    const int q0 = qb * 32;
+    if (q0 >= M) return;  // (no barriers in this kernel)
+    const int pos0 = pos_ptr[0];
+    const int qrow = min(q0 + lr, M - 1);
+    const int qpos = pos0 + q0 + lr;  // this lane's query position (rows past M are computed and dropped)
+    const float scale = 1.0f / sqrtf((float)HS);
+
+    bf16x8_t qf[KS];
+    const bf16_t* qp = q + (int64_t)qrow * ldq + (int64_t)h * HS + lh * 8;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) qf[ks] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(qp + ks * 16));
+
+    f32x16_t o[DT];
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[dt][r] = 0.f;
+    float m_run = -INFINITY, l_run = 0.f;
+
+    const bf16_t* kc = k_cache + (int64_t)g * S * HS;
+    const bf16_t* vg = vT + (int64_t)g * HS * Spad;
+    const int last_pos = pos0 + min(q0 + 31, M - 1);
+    const int n_kb = last_pos / 32 + 1;
+    for (int kb = 0; kb < n_kb; ++kb) {
+        // ---- scores of 32 keys x 32 queries
+        f32x16_t sacc;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sacc[r] = 0.f;
+        const bf16_t* kp = kc + (int64_t)min(kb * 32 + lr, S - 1) * HS + lh * 8;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const bf16x8_t kf = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(kp + ks * 16));
+            sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], sacc, 0, 0, 0);
+        }
+        // ---- causal mask + online softmax (this lane: query lr, keys kb*32 + (r&3) + 8 (r>>2) + 4 lh)
+        float mx = -INFINITY;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int key = kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+            const float s = key <= qpos ? sacc[r] * scale : -INFINITY;
+            sacc[r] = s;
+            mx = fmaxf(mx, s);
+        }
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        const float m_new = fmaxf(m_run, mx);  // finite: key 0 is visible to every query
+        const float alpha = __expf(m_run - m_new);
+        float lsum = 0.f;
+        float p[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            p[r] = __expf(sacc[r] - m_new);
+            lsum += p[r];
+        }
+        lsum += __shfl_xor(lsum, 32);
+        l_run = l_run * alpha + lsum;
+        m_run = m_new;
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
+        // ---- O^T += V^T . P^T
+        bf16x8_t pf[2];
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            uint32_t w[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) w[i] = (uint32_t)f2bf(p[8 * ks + 2 * i]) | ((uint32_t)f2bf(p[8 * ks + 2 * i + 1]) << 16);
+            pf[ks] = __builtin_bit_cast(bf16x8_t, make_uint4(w[0], w[1], w[2], w[3]));
+        }
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) {
+            const bf16_t* vp = vg + (int64_t)(dt * 32 + lr) * Spad + kb * 32 + 4 * lh;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const uint2 v0 = *reinterpret_cast<const uint2*>(vp + 16 * ks);      // keys 16 ks + 4 lh + 0..3
+                const uint2 v1 = *reinterpret_cast<const uint2*>(vp + 16 * ks + 8);  // keys 16 ks + 8 + 4 lh + 0..3
+                const bf16x8_t vf = __builtin_bit_cast(bf16x8_t, make_uint4(v0.x, v0.y, v1.x, v1.y));
+                o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[ks], o[dt], 0, 0, 0);
+            }
+        }
+    }
+    // ---- this lane: query lr, dims dt*32 + (r&3) + 8 (r>>2) + 4 lh
+    if (q0 + lr < M) {
+        const float inv = 1.0f / l_run;
+        bf16_t* yp = y + (int64_t)(q0 + lr) * ldy + (int64_t)h * HS + 4 * lh;
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const uint32_t w0 = (uint32_t)f2bf(o[dt][4 * c] * inv) | ((uint32_t)f2bf(o[dt][4 * c + 1] * inv) << 16);
+                const uint32_t w1 = (uint32_t)f2bf(o[dt][4 * c + 2] * inv) | ((uint32_t)f2bf(o[dt][4 * c + 3] * inv) << 16);
+                *reinterpret_cast<uint2*>(yp + dt * 32 + 8 * c) = make_uint2(w0, w1);
+            }
+    }
+}
+
+}  // namespace parrot
+
+using namespace parrot;
+
+extern "C" {
+
+int64_t parrot_attn_prefill_scratch_elems(int n_groups, int hs, int S) { return (int64_t)n_groups * hs * ((S + 63) / 64 * 64); }
+
+int parrot_attn_prefill(const void* q, int M, const int32_t* pos, const void* k_cache, const void* v_cache, void* vT_scratch, int n_groups,
+                        int q_per_kv, int hs, int S, void* y, int ldy, void* stream) {
+    PARROT_REQUIRE(q && pos && k_cache && v_cache && vT_scratch && y, "attn_prefill: null pointer");
+    PARROT_REQUIRE(M >= 1 && n_groups >= 1 && q_per_kv >= 1 && S >= 1 && M <= S, "attn_prefill: bad shape (M=%d S=%d)", M, S);
+    PARROT_REQUIRE(ldy >= n_groups * q_per_kv * hs && ldy % 4 == 0, "attn_prefill: ldy too small or not a multiple of 4");
+    PARROT_REQUIRE(aligned16(q) && aligned16(k_cache) && aligned16(v_cache) && aligned16(vT_scratch) && ((uintptr_t)y % 8 == 0),
+                   "attn_prefill: q / caches / scratch must be 16-byte aligned, y 8-byte aligned");
+    PARROT_UNSUPPORTED(hs == 32 || hs == 64 || hs == 128, "attn_prefill: head size %d not built (32, 64, 128)", hs);
+    hipStream_t st = (hipStream_t)stream;
+    const int Spad = (S + 63) / 64 * 64;
+    const int64_t nthreads = (int64_t)n_groups * (hs / 8) * Spad;
+    int rc = launch(K_ATTN_PREFILL_VT, attn_vt_kernel, dim3((unsigned)((nthreads + 255) / 256)), dim3(256), 0, st, (const bf16_t*)v_cache, pos, M,
+                    n_groups, hs, S, Spad, (bf16_t*)vT_scratch);
+    if (rc != PARROT_OK) return rc;
+    const int n_head = n_groups * q_per_kv, ldq = n_head * hs;
+    const dim3 grid((M + 127) / 128, n_head);
+#define PARROT_PF_GO(HSV)                                                                                                              \
+    return launch(K_ATTN_PREFILL, attn_prefill_kernel<HSV>, grid, dim3(256), 0, st, (const bf16_t*)q, ldq, M, pos, (const bf16_t*)k_cache, \
+                  (const bf16_t*)vT_scratch, n_groups, q_per_kv, S, Spad, (bf16_t*)y, ldy)
+    if (hs == 32) PARROT_PF_GO(32);
+    if (hs == 64) PARROT_PF_GO(64);
+    PARROT_PF_GO(128);
+#undef PARROT_PF_GO
+}
+
+}  // extern "C"

@@ -75,6 +75,8 @@ enum KernelId : int {
     K_GEMM_XSUM,
     K_GEMM_SPLITK,
     K_W4C_GEMM,
+    K_ATTN_PREFILL_VT,
+    K_ATTN_PREFILL,
     K_COUNT
 };
 

@@ -71,7 +71,11 @@ class DecodeSession:
         self.tokens[:T].copy_(prompt)
         self.pos.zero_()
         ws = self.model.workspace(T, self.device, 1)
-        logits = self.model.run_rows(ws, self.tokens, None, self.pos, self.S, self.caches, self.model.rope_cache)
+        ws.pos_is_zero = True  # the prompt starts at position 0: its attention may take the MFMA kernel (no ring wrap in the call)
+        try:
+            logits = self.model.run_rows(ws, self.tokens, None, self.pos, self.S, self.caches, self.model.rope_cache)
+        finally:
+            ws.pos_is_zero = False
         self.pos.fill_(T - 1)
         return logits
 

@@ -40,6 +40,7 @@ PARALLEL_BRANCHES = os.environ.get("PARROT_PARALLEL_BRANCHES", "1") != "0"
 # weights of the Linears that follow.  0 = off, 1 = out-projection, 2 = + MLP up-projection(s), 3 = + MLP down-projection.
 ATTN_PREFETCH = int(os.environ.get("PARROT_ATTN_PREFETCH", "0"))
 ATTN_PREFETCH_WGS = int(os.environ.get("PARROT_ATTN_PREFETCH_WGS", "224"))
+ATTN_PREFILL_MFMA = os.environ.get("PARROT_ATTN_PREFILL_MFMA", "1") != "0"  # prompts from position 0: parrot_attn_prefill
 
 
 def _streamed_weight(mod: nn.Module) -> Optional[torch.Tensor]:
@@ -317,7 +318,9 @@ class GPT(nn.Module):
                 caches = [tuple(torch.empty((c.n_query_groups, S, c.head_size), dtype=torch.bfloat16, device=idx.device)
                                 for _ in range(2))] * 1
                 caches = caches * c.n_layer  # the same scratch pair serves every layer in turn
+            ws.pos_is_zero = not use_kv_cache  # without a cache the rows are positions 0 .. T-1; with one, input_pos lives on the device
             logits = self.run_rows(ws, idx[b], None, pos if pos is not None else ws.zero_pos, S, caches, self.rope_cache)
+            ws.pos_is_zero = False
             out[b].copy_(logits)
         return out
 
@@ -420,6 +423,13 @@ class CausalSelfAttention(nn.Module):
                                          prefetch=prefetch, prefetch_wgs=ATTN_PREFETCH_WGS)
         ops.rope_kvappend(ws.qkv, rope[0], rope[1], c.rope_n_elem, pos, c.n_query_groups, c.q_per_kv, c.head_size, S,
                           ws.q, k_cache, v_cache, rope_local)
+        if (ATTN_PREFILL_MFMA and getattr(ws, "pos_is_zero", False) and ops.ATTN_PREFILL_MIN_ROWS <= ws.M <= S
+                and c.head_size in (32, 64, 128)):
+            # a prompt that starts at position 0 (no ring wrap inside the call): flash attention on the matrix cores
+            n = c.n_query_groups * c.head_size * ((S + 63) // 64 * 64)
+            if getattr(ws, "vt_scratch", None) is None or ws.vt_scratch.numel() < n:
+                ws.vt_scratch = torch.empty((n,), dtype=torch.bfloat16, device=ws.x.device)
+            return ops.attn_prefill(ws.q, pos, k_cache, v_cache, c.n_query_groups, c.q_per_kv, c.head_size, S, ws.y, ws.vt_scratch)
         return ops.attn_decode(ws.q, pos, k_cache, v_cache, c.n_query_groups, c.q_per_kv, c.head_size, S, nsplit,
                                ws.attn_ws(c, nsplit), ws.y)
 

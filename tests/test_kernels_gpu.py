@@ -618,6 +618,42 @@ def test_fused_decode_attention_with_prefetch_workgroups_is_unchanged(n_groups, 
             assert int(t2.abs().sum()) == 0
 
 
+@pytest.mark.parametrize("n_groups,q_per_kv,hs", [(4, 1, 128), (2, 4, 64), (1, 3, 32), (8, 16, 64)])
+@pytest.mark.parametrize("M,S,pos0", [(32, 32, 0), (100, 128, 0), (257, 300, 0), (70, 200, 37), (512, 512, 0)])
+def test_prefill_attention_on_the_matrix_cores_equals_the_row_by_row_path(n_groups, q_per_kv, hs, M, S, pos0):
+    """parrot_attn_prefill (flash attention, MFMA, P rounded to bf16) against parrot_attn_decode over the same rows (fp32 P) and
+    against float64 softmax attention: ragged last query block, a prompt that starts behind cached context (pos0 > 0, no wrap),
+    GQA / MQA head sharing, every head size."""
+    if n_groups * q_per_kv * hs * M > 16 * 128 * 512:
+        pytest.skip("kept small")
+    g = gen(24)
+    n_head = n_groups * q_per_kv
+    q = torch.randn(M, n_head * hs, generator=g).to(BF)
+    kc = torch.randn(n_groups, S, hs, generator=g).to(BF)
+    vc = torch.randn(n_groups, S, hs, generator=g).to(BF)
+    vc[:, pos0 + M:] = float("nan")  # slots behind the last key are never read as numbers
+    kc[:, pos0 + M:] = float("nan")
+    pos_d = torch.tensor([pos0], dtype=torch.int32, device=DEV)
+    y1 = torch.empty((M, n_head * hs), dtype=BF, device=DEV)
+    y2 = torch.empty_like(y1)
+    nsplit = 1
+    ops.attn_decode(q.to(DEV), pos_d, kc.to(DEV), vc.to(DEV), n_groups, q_per_kv, hs, S, nsplit, ops.attn_workspace(M, n_head, hs, nsplit, DEV), y1)
+    ops.attn_prefill(q.to(DEV), pos_d, kc.to(DEV), vc.to(DEV), n_groups, q_per_kv, hs, S, y2)
+    # float64 reference
+    qd = q.double().view(M, n_groups, q_per_kv, hs)
+    kd, vd = torch.nan_to_num(kc.double()), torch.nan_to_num(vc.double())
+    s = torch.einsum("mgqd,gsd->mgqs", qd, kd) / math.sqrt(hs)
+    mask = torch.arange(S)[None, :] <= (pos0 + torch.arange(M))[:, None]
+    s = s.masked_fill(~mask[:, None, None, :], float("-inf"))
+    want = torch.einsum("mgqs,gsd->mgqd", torch.softmax(s, dim=-1), vd).reshape(M, n_head * hs)
+    assert torch.isfinite(y2.float()).all()
+    err2 = float((y2.cpu().double() - want).abs().max())
+    err1 = float((y1.cpu().double() - want).abs().max())
+    assert err2 <= 2 ** -6, (err2, err1)  # values ~N(0,1): P and the output are rounded to bf16 (2^-8 relative each)
+    assert float((y2.cpu().double() - want).abs().mean()) <= 2e-3
+    assert float((y1.float() - y2.float()).abs().max()) <= 2 ** -5
+
+
 # ------------------------------------------------------------------------------------------------ step glue
 def test_embedding_and_argmax_advance():
     g = gen(18)
