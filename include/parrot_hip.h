@@ -142,6 +142,13 @@ int parrot_w8_gemv(const void* CB, const void* SCB, const void* xq, const void* 
 int parrot_w8_gemv_fused(const void* CB, const void* SCB, const void* x, float threshold, const void* bias,
                          const void* residual, void* out, int N, int K, int epilogue,
                          const parrot_norm_t* norm, void* stream);
+/* The same contract as parrot_w8_gemv for any M (prompts): v_mfma_i32_32x32x32_i8 on 128 x 128 tiles staged by LDS-DMA (K % 128 == 0;
+ * other shapes and M <= 8 forward to parrot_w8_gemv), exact int32 sums to `workspace` (parrot_w8_gemm_workspace_bytes bytes), then one
+ * element-wise pass: mm_dequant, outlier columns, epilogue - the GEMV's arithmetic.                                           */
+int64_t parrot_w8_gemm_workspace_bytes(int M, int N, int K, int epilogue);
+int parrot_w8_gemm(const void* CB, const void* SCB, const void* xq, const void* xout, const void* sca, const void* nout,
+                   const void* oidx, int M, const void* bias, const void* residual, int ldr, void* out, int ldo, int N, int K,
+                   int epilogue, void* workspace, void* stream);
 
 /* ---- norms (lit_gpt/rmsnorm.py:17-21; torch.nn.LayerNorm via lit_gpt/config.py:86-92) ---- */
 /* rsqrt_mode 0: rsqrt evaluated in fp32 and rounded to bf16 once (what torch's GPU kernels do);

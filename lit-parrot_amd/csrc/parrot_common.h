@@ -77,6 +77,8 @@ enum KernelId : int {
     K_W4C_GEMM,
     K_ATTN_PREFILL_VT,
     K_ATTN_PREFILL,
+    K_W8_GEMM,
+    K_W8_DEQUANT,
     K_COUNT
 };
 

@@ -666,6 +666,135 @@ w8_gemm_kernel(const int8_t* __restrict__ A, const int8_t* __restrict__ CB, cons
     }
 }
 
+// ------------------------------------------------------------------------------------------ int8 GEMM, second generation
+// The structure of gemm2.hip (128 x 128 tiles, both operands by global_load_lds_dwordx4 with the source-side swizzle, two LDS
+// buffers, one barrier per K-step, XCD-aware tile order is not needed at these sizes) with 128-byte K-steps = 128 int8 = four
+// v_mfma_i32_32x32x32_i8 per fragment pair.  The kernel only accumulates: it writes exact int32 sums (of its K range when K is
+// split) to the workspace, and w8_dequant_epilogue_kernel adds the ranges, dequantises, adds the outlier part and applies the
+// epilogue - the arithmetic of the GEMV, element for element (integer sums are order-free, so prompt and decode agree bit for bit
+// on the int8 part).
+typedef int i32x16b_t __attribute__((ext_vector_type(16)));
+typedef int i32x4b_t __attribute__((ext_vector_type(4)));
+
+__global__ void __launch_bounds__(256)
+w8_gemm2_kernel(const int8_t* __restrict__ A, const int8_t* __restrict__ CB, int M, int N, int K, int ksplit, int32_t* __restrict__ part) {
+    __shared__ __attribute__((aligned(1024))) uint4 smem[2][2][128 * 8];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int m0 = blockIdx.y * 128, n0 = blockIdx.x * 128, z = blockIdx.z;
+    const int lr = lane & 31, lh = lane >> 5;
+    const int ktiles = K / 128;
+    const int kt_begin = (int)((int64_t)z * ktiles / ksplit), kt_end = (int)((int64_t)(z + 1) * ktiles / ksplit);
+    const int l_row = lane >> 3, l_slot = lane & 7;
+    const int8_t* a_src[4];
+    const int8_t* b_src[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int r = (wave * 4 + i) * 8 + l_row;
+        const int gs = l_slot ^ ((r >> 1) & 7);
+        a_src[i] = A + (int64_t)min(m0 + r, M - 1) * K + gs * 16;
+        b_src[i] = CB + (int64_t)min(n0 + r, N - 1) * K + gs * 16;
+    }
+    auto issue = [&](int kt, int buf) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int r0 = (wave * 4 + i) * 8;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a_src[i] + (int64_t)kt * 128),
+                                             (__attribute__((address_space(3))) void*)&smem[buf][0][r0 * 8], 16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(b_src[i] + (int64_t)kt * 128),
+                                             (__attribute__((address_space(3))) void*)&smem[buf][1][r0 * 8], 16, 0, 0);
+        }
+    };
+    i32x16b_t acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0;
+    int a_row[2], b_row[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        a_row[i] = wm * 64 + i * 32 + lr;
+        b_row[i] = wn * 64 + i * 32 + lr;
+    }
+    if (kt_begin < kt_end) issue(kt_begin, 0);
+    for (int kt = kt_begin; kt < kt_end; ++kt) {
+        const int buf = (kt - kt_begin) & 1;
+        __syncthreads();  // (vmcnt(0) first) tile kt has landed; everybody is done with buffer buf ^ 1
+        if (kt + 1 < kt_end) issue(kt + 1, buf ^ 1);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {  // 32 int8 per MFMA: lane half lh holds bytes 16 lh .. 16 lh + 15 of the 32
+            const int slot = ks * 2 + lh;
+            i32x4b_t af[2], bfr[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                af[i] = __builtin_bit_cast(i32x4b_t, smem[buf][0][a_row[i] * 8 + (slot ^ ((a_row[i] >> 1) & 7))]);
+                bfr[i] = __builtin_bit_cast(i32x4b_t, smem[buf][1][b_row[i] * 8 + (slot ^ ((b_row[i] >> 1) & 7))]);
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_i32_32x32x32_i8(af[i], bfr[j], acc[i][j], 0, 0, 0);
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int col = n0 + wn * 64 + j * 32 + lr;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                if (row < M && col < N) part[((int64_t)z * M + row) * N + col] = acc[i][j][r];
+            }
+        }
+}
+
+// one thread per output element: sum of the K ranges (exact), mm_dequant, outlier part, epilogue (as w8_gemm_kernel / the GEMV)
+__global__ void __launch_bounds__(256)
+w8_dequant_epilogue_kernel(const int32_t* __restrict__ part, const int32_t* __restrict__ part2, int ksplit, const int8_t* __restrict__ CB,
+                           const int8_t* __restrict__ CB2, const float* __restrict__ SCB, const float* __restrict__ SCB2,
+                           const float* __restrict__ xout, const float* __restrict__ sca, const int32_t* __restrict__ nout,
+                           const int32_t* __restrict__ oidx, const bf16_t* __restrict__ bias, const bf16_t* residual, int ldr, bf16_t* out,
+                           int ldo, int M, int N, int K, int epi) {
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (int64_t)M * N) return;
+    const int row = (int)(t / N), col = (int)(t % N);
+    const float sa = sca[row];
+    const int no = nout[row];
+    float res[2] = {0.f, 0.f};
+    const int npass = epi == PARROT_EPI_SWIGLU ? 2 : 1;
+    for (int pass = 0; pass < npass; ++pass) {
+        const int32_t* p = pass ? part2 : part;
+        int32_t c = 0;
+        for (int z = 0; z < ksplit; ++z) c += p[((int64_t)z * M + row) * N + col];
+        const float scb = (pass ? SCB2 : SCB)[col];
+        const float b = (bias != nullptr && pass == 0) ? bf2f(bias[col]) : 0.f;
+        float v = rhalf(__fadd_rn(__fmul_rn(__fmul_rn(__fmul_rn((float)c, kMmDequant), sa), scb), b));
+        if (no > 0) {
+            const int8_t* wrow = (pass ? CB2 : CB) + (int64_t)col * K;
+            float o = 0.f;
+            for (int q = 0; q < no; ++q) {
+                const int k = oidx[(int64_t)row * K + q];
+                o += xout[(int64_t)row * K + k] * rhalf(__fdiv_rn(__fmul_rn((float)wrow[k], scb), 127.0f));
+            }
+            v = rhalf(v + rhalf(o));
+        }
+        res[pass] = v;
+    }
+    out[(int64_t)row * ldo + col] = apply_epilogue(epi, res[0], res[1], nullptr, residual ? residual + (int64_t)row * ldr : nullptr, col);
+}
+
+static int w8_gemm2_ksplit(int M, int N, int K) {
+    const int64_t tiles = (int64_t)((M + 127) / 128) * ((N + 127) / 128);
+    const int ktiles = K / 128;
+    int ks = tiles >= 192 ? 1 : (int)(512 / (tiles > 0 ? tiles : 1));
+    if (ks > 8) ks = 8;
+    while (ks > 1 && ktiles / ks < 4) --ks;
+    return ks < 1 ? 1 : ks;
+}
+
 }  // namespace parrot
 
 using namespace parrot;
@@ -759,6 +888,45 @@ int parrot_w8_gemv_fused(const void* CB, const void* SCB, const void* x, float t
     if (jn <= 2) return w8_fused_launch<2>(CB, CB2, SCB, SCB2, x, threshold, bias, residual, out, N, K, epilogue, nslabs, na, st);
     if (jn <= 3) return w8_fused_launch<3>(CB, CB2, SCB, SCB2, x, threshold, bias, residual, out, N, K, epilogue, nslabs, na, st);
     return w8_fused_launch<4>(CB, CB2, SCB, SCB2, x, threshold, bias, residual, out, N, K, epilogue, nslabs, na, st);
+}
+
+
+/* LLM.int8 prompt rows on the LDS-DMA structure: bytes of workspace parrot_w8_gemm needs (int32 sums per K range, x2 for SWIGLU) */
+int64_t parrot_w8_gemm_workspace_bytes(int M, int N, int K, int epilogue) {
+    if (M <= 8 || K % 128 != 0) return 0;
+    return (int64_t)w8_gemm2_ksplit(M, N, K) * M * N * 4 * (epilogue == PARROT_EPI_SWIGLU ? 2 : 1);
+}
+
+int parrot_w8_gemm(const void* CB, const void* SCB, const void* xq, const void* xout, const void* sca, const void* nout, const void* oidx,
+                   int M, const void* bias, const void* residual, int ldr, void* out, int ldo, int N, int K, int epilogue, void* workspace,
+                   void* stream) {
+    if (M <= 8 || K % 128 != 0)
+        return parrot_w8_gemv(CB, SCB, xq, xout, sca, nout, oidx, M, bias, residual, ldr, out, ldo, N, K, epilogue, stream);
+    PARROT_REQUIRE(CB && SCB && xq && xout && sca && nout && oidx && out && workspace, "w8_gemm: null pointer");
+    PARROT_REQUIRE(M <= 65535 * 128 && N >= 1, "w8_gemm: bad shape M=%d N=%d K=%d", M, N, K);
+    PARROT_REQUIRE(epilogue >= PARROT_EPI_NONE && epilogue <= PARROT_EPI_SWIGLU, "w8_gemm: unknown epilogue %d", epilogue);
+    PARROT_REQUIRE((epilogue == PARROT_EPI_RESIDUAL) == (residual != nullptr), "w8_gemm: residual iff RESIDUAL epilogue");
+    PARROT_REQUIRE(aligned16(CB) && aligned16(xq), "w8_gemm: CB and xq must be 16-byte aligned");
+    PARROT_UNSUPPORTED(!(epilogue == PARROT_EPI_SWIGLU && bias), "w8_gemm: SWIGLU epilogue takes no bias");
+    hipStream_t st = (hipStream_t)stream;
+    const bool swi = epilogue == PARROT_EPI_SWIGLU;
+    const int8_t* CB2 = swi ? (const int8_t*)CB + (int64_t)N * K : nullptr;
+    const float* SCB2 = swi ? (const float*)SCB + N : nullptr;
+    const int ks = w8_gemm2_ksplit(M, N, K);
+    int32_t* part = (int32_t*)workspace;
+    int32_t* part2 = swi ? part + (int64_t)ks * M * N : nullptr;
+    const dim3 grid((N + 127) / 128, (M + 127) / 128, ks);
+    int rc = launch(K_W8_GEMM, w8_gemm2_kernel, grid, dim3(256), 0, st, (const int8_t*)xq, (const int8_t*)CB, M, N, K, ks, part);
+    if (rc != PARROT_OK) return rc;
+    if (swi) {
+        rc = launch(K_W8_GEMM, w8_gemm2_kernel, grid, dim3(256), 0, st, (const int8_t*)xq, CB2, M, N, K, ks, part2);
+        if (rc != PARROT_OK) return rc;
+    }
+    const int64_t mn = (int64_t)M * N;
+    return launch(K_W8_DEQUANT, w8_dequant_epilogue_kernel, dim3((unsigned)((mn + 255) / 256)), dim3(256), 0, st, (const int32_t*)part,
+                  (const int32_t*)part2, ks, (const int8_t*)CB, CB2, (const float*)SCB, SCB2, (const float*)xout, (const float*)sca,
+                  (const int32_t*)nout, (const int32_t*)oidx, (const bf16_t*)bias, (const bf16_t*)residual, ldr, (bf16_t*)out, ldo, M, N, K,
+                  epilogue);
 }
 
 }  // extern "C"

@@ -4,6 +4,7 @@ Everything here enqueues HIP kernels on the current torch stream and returns imm
 torch implementation.  Activations are bf16 rows ``(M, features)`` of ONE sequence.
 """
 import ctypes as C
+import os
 from typing import Optional
 
 import torch
@@ -220,9 +221,20 @@ def w8_prep_act(x: torch.Tensor, threshold: float, act: W8Act, norm: Optional[No
     return act
 
 
+W8_PREFILL_GEMM2 = os.environ.get("PARROT_W8_GEMM2", "1") != "0"  # False: the first-generation int8 GEMM inside parrot_w8_gemv (A/B, tests)
+
+
 def w8_linear(CB: torch.Tensor, SCB: torch.Tensor, N: int, K: int, act: W8Act, out: torch.Tensor, *, bias=None,
               epilogue=EPI_NONE, residual=None) -> torch.Tensor:
     _rows(out, "w8_linear")
+    lib = _hip.load()
+    nws = int(lib.parrot_w8_gemm_workspace_bytes(act.M, N, K, epilogue)) if W8_PREFILL_GEMM2 else 0
+    if nws > 0:  # prompts: int8 MFMA GEMM on the LDS-DMA structure + element-wise dequantise / outlier / epilogue pass
+        ws = torch.empty((nws,), dtype=torch.uint8, device=out.device)
+        check(lib.parrot_w8_gemm(ptr(CB), ptr(SCB), ptr(act.xq), ptr(act.xout), ptr(act.sca), ptr(act.nout), ptr(act.oidx), act.M,
+                                 ptr(_opt_vec(bias, N, "bias")), ptr(residual), residual.stride(0) if residual is not None else 0,
+                                 ptr(out), out.stride(0), N, K, epilogue, ptr(ws), stream()), "parrot_w8_gemm")
+        return out
     check(_hip.load().parrot_w8_gemv(ptr(CB), ptr(SCB), ptr(act.xq), ptr(act.xout), ptr(act.sca), ptr(act.nout), ptr(act.oidx), act.M,
                                      ptr(_opt_vec(bias, N, "bias")), ptr(residual),
                                      residual.stride(0) if residual is not None else 0, ptr(out), out.stride(0), N, K,

@@ -350,6 +350,36 @@ def test_w8_linear_matches_oracle(N, K, outliers, M):
     assert_bf16_close(out, want.float(), ulps=1 if outliers else 0, atol=0.0, what=f"w8 {N}x{K} outliers={outliers}")
 
 
+@pytest.mark.parametrize("M,N,K,epi", [(130, 300, 512, EPI_NONE), (64, 520, 11008, EPI_RESIDUAL), (300, 2300, 256, EPI_SWIGLU), (1100, 3000, 128, EPI_GELU)])
+def test_w8_prompt_gemm_on_the_lds_dma_structure_equals_the_first_generation_bit_for_bit(M, N, K, epi):
+    """parrot_w8_gemm (128 x 128 tiles by LDS-DMA, exact int32 sums to a workspace, element-wise dequantise / outlier / epilogue pass;
+    split and unsplit K, ragged tiles, SwiGLU over [fc_1; fc_2]) against the first-generation int8 GEMM and the oracle: the integer
+    part is order-free and the element-wise arithmetic is the same code, so the two agree bit for bit."""
+    g = gen(14)
+    swi = epi == EPI_SWIGLU
+    W = (torch.randn(N * (2 if swi else 1), K, generator=g) * 0.02).to(BF)
+    x = torch.randn(M, K, generator=g).to(BF)
+    x[0, 3], x[M // 2, K - 1], x[M - 1, 17] = 9.5, -7.25, 6.0
+    res = torch.randn(M, N, generator=g).to(BF)
+    bias = None if swi else (torch.randn(N, generator=g) * 0.1).to(BF)
+    cb, scb = o8.quantize_weight_rows(W)
+    act = ops.w8_prep_act(x.to(DEV), 6.0, ops.W8Act(M, K, DEV))
+    outs = []
+    for new in (True, False):
+        ops.W8_PREFILL_GEMM2 = new
+        try:
+            out = torch.full((M + 1, N), 7.0, dtype=BF, device=DEV)
+            ops.w8_linear(cb.to(DEV), scb.to(DEV), N, K, act, out[:M], bias=bias.to(DEV) if bias is not None else None, epilogue=epi,
+                          residual=res.to(DEV) if epi == EPI_RESIDUAL else None)
+        finally:
+            ops.W8_PREFILL_GEMM2 = True
+        assert torch.all(out[M] == 7.0)
+        outs.append(out[:M].clone())
+    assert torch.equal(outs[0], outs[1]), f"{int((outs[0] != outs[1]).sum())} elements differ"
+    if epi == EPI_NONE:
+        assert_bf16_close(outs[0], o8.linear(x, cb, scb, bias, 6.0).float(), ulps=1, atol=0.0, what="w8 gemm2 vs oracle")
+
+
 @pytest.mark.parametrize("N,K", [(64, 256), (96, 4096), (40, 352), (16, 11008), (20000, 512), (24, 16384)])
 @pytest.mark.parametrize("outliers", [0, 3, 400])
 def test_w8_fused_single_row_matches_oracle_and_the_two_launch_path(N, K, outliers):
