@@ -25,7 +25,11 @@ import sys
 import time
 from pathlib import Path
 
-import torch
+# the pool's driver only supports dmabuf IPC: RCCL (the timing barrier at N > 1) fails with the legacy mode
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+
+import torch  # noqa: E402
 
 REPO = Path(__file__).resolve().parent
 if str(REPO) not in sys.path:
