@@ -79,6 +79,7 @@ enum KernelId : int {
     K_ATTN_PREFILL,
     K_W8_GEMM,
     K_W8_DEQUANT,
+    K_W8_OUTLIER,
     K_COUNT
 };
 

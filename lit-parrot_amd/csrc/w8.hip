@@ -10,6 +10,8 @@
 // Rows of a multi-row call are treated independently (== M separate single-token calls).
 #include <hip/hip_fp16.h>
 
+#include <stdlib.h>
+
 #include "parrot_common.h"
 
 namespace parrot {
@@ -751,16 +753,82 @@ w8_gemm2_kernel(const int8_t* __restrict__ A, const int8_t* __restrict__ CB, int
         }
 }
 
+// Outlier part of the prompt rows: O[row][col] = sum over the row's outlier columns k (ascending list order, as the GEMV) of
+// xout[row][k] * fp16(CB[col][k] * SCB[col] / 127).  LANES ARE ROWS: the 64 rows of a wave read the same 1-byte-wide weight row
+// CB[col][:] at their own outlier positions, so the fetches of a wave stay inside one K-byte row (and the rows of a prompt mostly
+// share their outlier columns).  With lanes as columns (first version, inside the element-wise pass) every lane touched its own
+// weight row: 256 x n_outliers cache lines per workgroup - the MLP down-projection (37 outlier columns per row on the synthetic
+// model) took 0.4 ms per launch at 512 rows.  A workgroup = 64 rows x 16 columns, transposed through LDS for the store.
+__global__ void __launch_bounds__(256)
+w8_outlier_kernel(const int8_t* __restrict__ CB, const float* __restrict__ SCB, const float* __restrict__ xout, const int32_t* __restrict__ nout,
+                  const int32_t* __restrict__ oidx, float* __restrict__ O, int M, int N, int K) {
+    __shared__ float tile[64][17];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int row = blockIdx.y * 64 + lane, rowc = min(row, M - 1);
+    const int no = row < M ? nout[rowc] : 0;
+    int no_max = no;
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) no_max = max(no_max, __shfl_xor(no_max, off));
+    if (__syncthreads_or(no_max > 0) == 0) return;  // nobody in this 64-row block has outliers: the element-wise pass will not read O
+    const int32_t* ip = oidx + (int64_t)rowc * K;
+    const float* xp = xout + (int64_t)rowc * K;
+    const int8_t* wrow[4];
+    float scb[4], o[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const int col = min((int)blockIdx.x * 16 + wave * 4 + c, N - 1);
+        wrow[c] = CB + (int64_t)col * K;
+        scb[c] = SCB[col];
+    }
+    // eight outliers at a time: their indices, then their activations and the 4 x 8 weight bytes are all in flight together (one at
+    // a time the loop was a chain of three dependent loads per outlier: 31 us per launch); the sums keep the list order
+    for (int q0 = 0; q0 < no_max; q0 += 8) {
+        int kk[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {  // entries past this row's list: column 0 (a valid address; masked at the sum) - the list
+            const int k = q0 + i < no ? ip[q0 + i] : 0;  // itself is only defined up to nout[row]
+            kk[i] = min(max(k, 0), K - 1);
+        }
+        float xv[8];
+        float wv[4][8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            xv[i] = xp[kk[i]];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) wv[c][i] = (float)wrow[c][kk[i]];
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            if (q0 + i < no) {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) o[c] += xv[i] * rhalf(__fdiv_rn(__fmul_rn(wv[c][i], scb[c]), 127.0f));
+            }
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < 4; ++c) tile[lane][wave * 4 + c] = o[c];
+    __syncthreads();
+    // 64 rows x 16 columns: thread t stores 4 consecutive columns of row t / 4
+    const int r = threadIdx.x >> 2, c4 = (threadIdx.x & 3) * 4;
+    const int grow = blockIdx.y * 64 + r;
+    if (grow < M) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int gcol = blockIdx.x * 16 + c4 + i;
+            if (gcol < N) O[(int64_t)grow * N + gcol] = tile[r][c4 + i];
+        }
+    }
+}
+
 // one thread per output element: sum of the K ranges (exact), mm_dequant, outlier part, epilogue (as w8_gemm_kernel / the GEMV)
 __global__ void __launch_bounds__(256)
 w8_dequant_epilogue_kernel(const int32_t* __restrict__ part, const int32_t* __restrict__ part2, int ksplit, const int8_t* __restrict__ CB,
                            const int8_t* __restrict__ CB2, const float* __restrict__ SCB, const float* __restrict__ SCB2,
-                           const float* __restrict__ xout, const float* __restrict__ sca, const int32_t* __restrict__ nout,
-                           const int32_t* __restrict__ oidx, const bf16_t* __restrict__ bias, const bf16_t* residual, int ldr, bf16_t* out,
+                           const float* __restrict__ O1, const float* __restrict__ O2, const float* __restrict__ sca,
+                           const int32_t* __restrict__ nout, const bf16_t* __restrict__ bias, const bf16_t* residual, int ldr, bf16_t* out,
                            int ldo, int M, int N, int K, int epi) {
-    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= (int64_t)M * N) return;
-    const int row = (int)(t / N), col = (int)(t % N);
+    const int row = blockIdx.y, col = blockIdx.x * 256 + threadIdx.x;  // (a flat index cost a 64-bit division per element)
+    if (col >= N) return;
     const float sa = sca[row];
     const int no = nout[row];
     float res[2] = {0.f, 0.f};
@@ -772,15 +840,7 @@ w8_dequant_epilogue_kernel(const int32_t* __restrict__ part, const int32_t* __re
         const float scb = (pass ? SCB2 : SCB)[col];
         const float b = (bias != nullptr && pass == 0) ? bf2f(bias[col]) : 0.f;
         float v = rhalf(__fadd_rn(__fmul_rn(__fmul_rn(__fmul_rn((float)c, kMmDequant), sa), scb), b));
-        if (no > 0) {
-            const int8_t* wrow = (pass ? CB2 : CB) + (int64_t)col * K;
-            float o = 0.f;
-            for (int q = 0; q < no; ++q) {
-                const int k = oidx[(int64_t)row * K + q];
-                o += xout[(int64_t)row * K + k] * rhalf(__fdiv_rn(__fmul_rn((float)wrow[k], scb), 127.0f));
-            }
-            v = rhalf(v + rhalf(o));
-        }
+        if (no > 0) v = rhalf(v + rhalf((pass ? O2 : O1)[(int64_t)row * N + col]));  // w8_outlier_kernel's sum
         res[pass] = v;
     }
     out[(int64_t)row * ldo + col] = apply_epilogue(epi, res[0], res[1], nullptr, residual ? residual + (int64_t)row * ldr : nullptr, col);
@@ -789,7 +849,12 @@ w8_dequant_epilogue_kernel(const int32_t* __restrict__ part, const int32_t* __re
 static int w8_gemm2_ksplit(int M, int N, int K) {
     const int64_t tiles = (int64_t)((M + 127) / 128) * ((N + 127) / 128);
     const int ktiles = K / 128;
-    int ks = tiles >= 192 ? 1 : (int)(512 / (tiles > 0 ? tiles : 1));
+    static int target = -1;  // PARROT_W8_SPLIT_TARGET: workgroups to aim at when splitting K
+    if (target < 0) {
+        const char* e = getenv("PARROT_W8_SPLIT_TARGET");
+        target = e ? atoi(e) : 512;
+    }
+    int ks = tiles >= 192 ? 1 : (int)(target / (tiles > 0 ? tiles : 1));
     if (ks > 8) ks = 8;
     while (ks > 1 && ktiles / ks < 4) --ks;
     return ks < 1 ? 1 : ks;
@@ -894,7 +959,7 @@ int parrot_w8_gemv_fused(const void* CB, const void* SCB, const void* x, float t
 /* LLM.int8 prompt rows on the LDS-DMA structure: bytes of workspace parrot_w8_gemm needs (int32 sums per K range, x2 for SWIGLU) */
 int64_t parrot_w8_gemm_workspace_bytes(int M, int N, int K, int epilogue) {
     if (M <= 8 || K % 128 != 0) return 0;
-    return (int64_t)w8_gemm2_ksplit(M, N, K) * M * N * 4 * (epilogue == PARROT_EPI_SWIGLU ? 2 : 1);
+    return ((int64_t)w8_gemm2_ksplit(M, N, K) + 1) * M * N * 4 * (epilogue == PARROT_EPI_SWIGLU ? 2 : 1);  // int32 sums + fp32 outlier part
 }
 
 int parrot_w8_gemm(const void* CB, const void* SCB, const void* xq, const void* xout, const void* sca, const void* nout, const void* oidx,
@@ -922,10 +987,21 @@ int parrot_w8_gemm(const void* CB, const void* SCB, const void* xq, const void* 
         rc = launch(K_W8_GEMM, w8_gemm2_kernel, grid, dim3(256), 0, st, (const int8_t*)xq, CB2, M, N, K, ks, part2);
         if (rc != PARROT_OK) return rc;
     }
-    const int64_t mn = (int64_t)M * N;
-    return launch(K_W8_DEQUANT, w8_dequant_epilogue_kernel, dim3((unsigned)((mn + 255) / 256)), dim3(256), 0, st, (const int32_t*)part,
-                  (const int32_t*)part2, ks, (const int8_t*)CB, CB2, (const float*)SCB, SCB2, (const float*)xout, (const float*)sca,
-                  (const int32_t*)nout, (const int32_t*)oidx, (const bf16_t*)bias, (const bf16_t*)residual, ldr, (bf16_t*)out, ldo, M, N, K,
+    PARROT_REQUIRE(M <= 65535, "w8_gemm: M too large");
+    float* O1 = (float*)(part + (int64_t)ks * M * N * (swi ? 2 : 1));
+    float* O2 = swi ? O1 + (int64_t)M * N : nullptr;
+    const dim3 ogrid((unsigned)((N + 15) / 16), (unsigned)((M + 63) / 64));
+    rc = launch(K_W8_OUTLIER, w8_outlier_kernel, ogrid, dim3(256), 0, st, (const int8_t*)CB, (const float*)SCB, (const float*)xout,
+                (const int32_t*)nout, (const int32_t*)oidx, O1, M, N, K);
+    if (rc != PARROT_OK) return rc;
+    if (swi) {
+        rc = launch(K_W8_OUTLIER, w8_outlier_kernel, ogrid, dim3(256), 0, st, CB2, SCB2, (const float*)xout, (const int32_t*)nout,
+                    (const int32_t*)oidx, O2, M, N, K);
+        if (rc != PARROT_OK) return rc;
+    }
+    return launch(K_W8_DEQUANT, w8_dequant_epilogue_kernel, dim3((unsigned)((N + 255) / 256), (unsigned)M), dim3(256), 0, st, (const int32_t*)part,
+                  (const int32_t*)part2, ks, (const int8_t*)CB, CB2, (const float*)SCB, SCB2, (const float*)O1, (const float*)O2,
+                  (const float*)sca, (const int32_t*)nout, (const bf16_t*)bias, (const bf16_t*)residual, ldr, (bf16_t*)out, ldo, M, N, K,
                   epilogue);
 }
 
