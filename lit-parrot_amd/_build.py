@@ -29,19 +29,39 @@ def needs_build() -> bool:
     return newest > LIB_PATH.stat().st_mtime
 
 
+def _compile_one(args):
+    exe, src, obj, verbose = args
+    cmd = [exe, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", "-Wall", "-Wno-unused-function", "-c", src, "-o", obj]
+    if verbose:
+        print(" ".join(cmd))
+    proc = subprocess.run(cmd, capture_output=True, text=True)
+    return src, proc.returncode, proc.stdout + proc.stderr
+
+
 def build(force: bool = False, verbose: bool = False) -> Path:
-    """Build libparrot_hip.so if it is missing or older than its sources."""
+    """Build libparrot_hip.so if it is missing or older than its sources: one hipcc -c per source file, in parallel, then a link."""
     if not force and not needs_build():
         return LIB_PATH
-    srcs = [str(CSRC / s) for s in SOURCES if (CSRC / s).exists()]
+    from concurrent.futures import ThreadPoolExecutor
+
+    exe = _hipcc()
+    objdir = PKG_DIR / "build"
+    objdir.mkdir(exist_ok=True)
+    srcs = [CSRC / s for s in SOURCES if (CSRC / s).exists()]
+    jobs = [(exe, str(src), str(objdir / (src.stem + ".o")), verbose) for src in srcs]
+    workers = max(1, min(len(jobs), (os.cpu_count() or 2)))
+    with ThreadPoolExecutor(max_workers=workers) as pool:
+        results = list(pool.map(_compile_one, jobs))
+    failed = [(src, out) for src, rc, out in results if rc != 0]
+    if failed:
+        raise RuntimeError("hipcc failed:\n" + "\n".join(f"--- {src}\n{out}" for src, out in failed))
     tmp = LIB_PATH.with_suffix(".so.tmp")
-    cmd = [_hipcc(), f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-shared", "-fgpu-rdc" if False else "-fno-gpu-rdc",
-           "-Wall", "-Wno-unused-function", "-o", str(tmp)] + srcs
+    cmd = [exe, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-fno-gpu-rdc", "-o", str(tmp)] + [j[2] for j in jobs]
     if verbose:
         print(" ".join(cmd))
     proc = subprocess.run(cmd, capture_output=True, text=True)
     if proc.returncode != 0:
-        raise RuntimeError(f"hipcc failed:\n{proc.stdout}\n{proc.stderr}")
+        raise RuntimeError(f"hipcc link failed:\n{proc.stdout}\n{proc.stderr}")
     os.replace(tmp, LIB_PATH)
     return LIB_PATH
 
