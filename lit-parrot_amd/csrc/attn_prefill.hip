@@ -13,6 +13,8 @@
 // (zero beyond the last key, so that masked columns multiply finite numbers).  Requires *pos + M <= S (no ring wrap inside the
 // call): the prompt of generate().  P is rounded to bf16 before P.V (torch's flash kernels do the same; the decode kernels keep
 // P in fp32): results agree with the multi-row decode path to bf16 rounding.
+#include <stdlib.h>
+
 #include "parrot_common.h"
 
 namespace parrot {
@@ -150,6 +152,158 @@ attn_prefill_kernel(const bf16_t* __restrict__ q, int ldq, int M, const int32_t*
     }
 }
 
+// The same computation with the key / value blocks shared by the four waves of a workgroup through LDS (four consecutive query
+// blocks of one head): each wave of the kernel above streams its own copy of K and V^T from L2 - 16 KB per 16 MFMAs, four times
+// what a CU's vector-memory path sustains - here a block is fetched once per workgroup.  Rows are padded so that the fragment
+// reads are conflict-free: K rows by 16 B (a ds_read_b128 lane group reads 16 consecutive-ish rows: slot = row mod 16), V^T rows
+// (32 keys = 64 B) to 72 B (a ds_read_b64 half-wave reads 32 dims: 18 * dim mod 64 are 32 distinct even banks).
+// The next block travels global -> registers while the current one is multiplied, and is written behind a barrier.
+template <int HS>
+__global__ void __launch_bounds__(256)
+attn_prefill_lds_kernel(const bf16_t* __restrict__ q, int ldq, int M, const int32_t* __restrict__ pos_ptr, const bf16_t* __restrict__ k_cache,
+                        const bf16_t* __restrict__ vT, int n_groups, int q_per_kv, int S, int Spad, bf16_t* __restrict__ y, int ldy) {
+    constexpr int KS = HS / 16, DT = HS / 32;
+    constexpr int KLD = HS + 8;  // K row stride in elements (16-byte pad)
+    constexpr int VLD = 36;      // V^T row stride in elements (72 B)
+    constexpr int KPT = HS / 64;  // 16-byte pieces of the K block per thread (32 rows x HS*2 B / 256 threads / 16 B)
+    constexpr int VPT = HS / 64;  // 16-byte pieces of the V^T block per thread (HS rows x 64 B / 256 threads / 16 B)
+    static_assert(HS == 64 || HS == 128, "the LDS kernel is built for head sizes 64 and 128");
+    __shared__ __attribute__((aligned(16))) bf16_t Ks[32 * KLD];
+    __shared__ __attribute__((aligned(16))) bf16_t Vs[HS * VLD];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int lr = lane & 31, lh = lane >> 5;
+    const int h = blockIdx.y, g = h / q_per_kv;
+    const int wg = (int)gridDim.x - 1 - (int)blockIdx.x;  // late (long) query blocks first
+    const int q0 = (wg * 4 + wave) * 32;
+    const bool live = q0 < M;
+    const int pos0 = pos_ptr[0];
+    const int qrow = min(q0 + lr, M - 1);
+    const int qpos = pos0 + q0 + lr;
+    const float scale = 1.0f / sqrtf((float)HS);
+
+    bf16x8_t qf[KS];
+    const bf16_t* qp = q + (int64_t)qrow * ldq + (int64_t)h * HS + lh * 8;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) qf[ks] = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(qp + ks * 16));
+    f32x16_t o[DT];
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[dt][r] = 0.f;
+    float m_run = -INFINITY, l_run = 0.f;
+
+    const bf16_t* kc = k_cache + (int64_t)g * S * HS;
+    const bf16_t* vg = vT + (int64_t)g * HS * Spad;
+    const int my_kb = live ? (pos0 + min(q0 + 31, M - 1)) / 32 + 1 : 0;          // key blocks this wave needs
+    const int wg_last_q = min(wg * 128 + 127, M - 1);
+    const int n_kb = (pos0 + wg_last_q) / 32 + 1;                                   // ... and the workgroup (wave-uniform)
+    // staging assignment: K piece p of thread t: row (t * KPT + p) / (HS / 8), 16-byte column (t * KPT + p) % (HS / 8);
+    //                     V^T piece: dim (t * VPT + p) / 4, 16-byte column (t * VPT + p) % 4 (8 keys)
+    uint4 rk[KPT], rv[VPT];
+    auto fetch = [&](int kb) {
+#pragma unroll
+        for (int p = 0; p < KPT; ++p) {
+            const int idx = tid * KPT + p, row = idx / (HS / 8), c = idx % (HS / 8);
+            rk[p] = *reinterpret_cast<const uint4*>(kc + (int64_t)min(kb * 32 + row, S - 1) * HS + c * 8);
+        }
+#pragma unroll
+        for (int p = 0; p < VPT; ++p) {
+            const int idx = tid * VPT + p, dim = idx / 4, c = idx % 4;
+            rv[p] = *reinterpret_cast<const uint4*>(vg + (int64_t)dim * Spad + kb * 32 + c * 8);
+        }
+    };
+    auto stage = [&]() {
+#pragma unroll
+        for (int p = 0; p < KPT; ++p) {
+            const int idx = tid * KPT + p, row = idx / (HS / 8), c = idx % (HS / 8);
+            *reinterpret_cast<uint4*>(&Ks[row * KLD + c * 8]) = rk[p];
+        }
+#pragma unroll
+        for (int p = 0; p < VPT; ++p) {
+            const int idx = tid * VPT + p, dim = idx / 4, c = idx % 4;
+            uint2* dst = reinterpret_cast<uint2*>(&Vs[dim * VLD + c * 8]);  // 72-byte rows: 8-byte aligned
+            dst[0] = make_uint2(rv[p].x, rv[p].y);
+            dst[1] = make_uint2(rv[p].z, rv[p].w);
+        }
+    };
+    fetch(0);
+    stage();
+    __syncthreads();
+    for (int kb = 0; kb < n_kb; ++kb) {
+        if (kb + 1 < n_kb) fetch(kb + 1);
+        if (kb < my_kb) {
+            f32x16_t sacc;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) sacc[r] = 0.f;
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const bf16x8_t kf = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(&Ks[lr * KLD + ks * 16 + lh * 8]));
+                sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], sacc, 0, 0, 0);
+            }
+            float mx = -INFINITY;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int key = kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                const float sv = key <= qpos ? sacc[r] * scale : -INFINITY;
+                sacc[r] = sv;
+                mx = fmaxf(mx, sv);
+            }
+            mx = fmaxf(mx, __shfl_xor(mx, 32));
+            const float m_new = fmaxf(m_run, mx);
+            const float alpha = __expf(m_run - m_new);
+            float lsum = 0.f, p[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                p[r] = __expf(sacc[r] - m_new);
+                lsum += p[r];
+            }
+            lsum += __shfl_xor(lsum, 32);
+            l_run = l_run * alpha + lsum;
+            m_run = m_new;
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
+            bf16x8_t pf[2];
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                uint32_t w[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) w[i] = (uint32_t)f2bf(p[8 * ks + 2 * i]) | ((uint32_t)f2bf(p[8 * ks + 2 * i + 1]) << 16);
+                pf[ks] = __builtin_bit_cast(bf16x8_t, make_uint4(w[0], w[1], w[2], w[3]));
+            }
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) {
+                const bf16_t* vp = &Vs[(dt * 32 + lr) * VLD + 4 * lh];
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) {
+                    const uint2 v0 = *reinterpret_cast<const uint2*>(vp + 16 * ks);
+                    const uint2 v1 = *reinterpret_cast<const uint2*>(vp + 16 * ks + 8);
+                    const bf16x8_t vf = __builtin_bit_cast(bf16x8_t, make_uint4(v0.x, v0.y, v1.x, v1.y));
+                    o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[ks], o[dt], 0, 0, 0);
+                }
+            }
+        }
+        __syncthreads();  // everybody is done with this block's LDS image
+        if (kb + 1 < n_kb) {
+            stage();
+            __syncthreads();
+        }
+    }
+    if (live && q0 + lr < M) {
+        const float inv = 1.0f / l_run;
+        bf16_t* yp = y + (int64_t)(q0 + lr) * ldy + (int64_t)h * HS + 4 * lh;
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const uint32_t w0 = (uint32_t)f2bf(o[dt][4 * c] * inv) | ((uint32_t)f2bf(o[dt][4 * c + 1] * inv) << 16);
+                const uint32_t w1 = (uint32_t)f2bf(o[dt][4 * c + 2] * inv) | ((uint32_t)f2bf(o[dt][4 * c + 3] * inv) << 16);
+                *reinterpret_cast<uint2*>(yp + dt * 32 + 8 * c) = make_uint2(w0, w1);
+            }
+    }
+}
+
 }  // namespace parrot
 
 using namespace parrot;
@@ -174,6 +328,19 @@ int parrot_attn_prefill(const void* q, int M, const int32_t* pos, const void* k_
     if (rc != PARROT_OK) return rc;
     const int n_head = n_groups * q_per_kv, ldq = n_head * hs;
     const dim3 grid((M + 127) / 128, n_head);
+    static int use_lds = -1;  // PARROT_ATTN_PREFILL_LDS=0: every wave streams its own K / V^T (A/B)
+    if (use_lds < 0) {
+        const char* e = getenv("PARROT_ATTN_PREFILL_LDS");
+        use_lds = e ? atoi(e) : 1;
+    }
+#define PARROT_PF_LDS_GO(HSV)                                                                                                              \
+    return launch(K_ATTN_PREFILL, attn_prefill_lds_kernel<HSV>, grid, dim3(256), 0, st, (const bf16_t*)q, ldq, M, pos, (const bf16_t*)k_cache, \
+                  (const bf16_t*)vT_scratch, n_groups, q_per_kv, S, Spad, (bf16_t*)y, ldy)
+    if (use_lds && M > 128) {  // (one query block per workgroup has nothing to share)
+        if (hs == 64) PARROT_PF_LDS_GO(64);
+        if (hs == 128) PARROT_PF_LDS_GO(128);
+    }
+#undef PARROT_PF_LDS_GO
 #define PARROT_PF_GO(HSV)                                                                                                              \
     return launch(K_ATTN_PREFILL, attn_prefill_kernel<HSV>, grid, dim3(256), 0, st, (const bf16_t*)q, ldq, M, pos, (const bf16_t*)k_cache, \
                   (const bf16_t*)vT_scratch, n_groups, q_per_kv, S, Spad, (bf16_t*)y, ldy)
