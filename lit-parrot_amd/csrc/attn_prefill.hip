@@ -336,7 +336,7 @@ int parrot_attn_prefill(const void* q, int M, const int32_t* pos, const void* k_
 #define PARROT_PF_LDS_GO(HSV)                                                                                                              \
     return launch(K_ATTN_PREFILL, attn_prefill_lds_kernel<HSV>, grid, dim3(256), 0, st, (const bf16_t*)q, ldq, M, pos, (const bf16_t*)k_cache, \
                   (const bf16_t*)vT_scratch, n_groups, q_per_kv, S, Spad, (bf16_t*)y, ldy)
-    if (use_lds && M > 128) {  // (one query block per workgroup has nothing to share)
+    if (use_lds && M > 32) {  // (a single query block has nothing to share)
         if (hs == 64) PARROT_PF_LDS_GO(64);
         if (hs == 128) PARROT_PF_LDS_GO(128);
     }

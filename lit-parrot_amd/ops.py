@@ -311,8 +311,9 @@ def attn_prefill(q: torch.Tensor, pos: torch.Tensor, k_cache: torch.Tensor, v_ca
     return y
 
 
-ATTN_PREFILL_MIN_ROWS = 160  # prompts from this many rows take the MFMA kernel when the caller rules out a ring wrap (at 128 rows
-# the row-by-row kernels are level: 0.38 vs 0.56 ms on Llama-2-7B; at 512: 1.9 vs 0.84 ms on StableLM-3B)
+# prompts from this many rows take the MFMA kernel when the caller rules out a ring wrap (measured on Llama-2-7B, 128 rows: row-by-row
+# kernels 0.38 ms, flash kernel 0.56 ms without / see DESIGN.md 4c with LDS sharing; StableLM-3B, 512 rows: 1.9 vs 0.54 ms)
+ATTN_PREFILL_MIN_ROWS = int(os.environ.get("PARROT_ATTN_PREFILL_MIN_ROWS", "160"))
 
 
 def attn_fused_decode(qkv: torch.Tensor, cos: torch.Tensor, sin: torch.Tensor, n_elem: int, pos: torch.Tensor,
