@@ -577,9 +577,16 @@ int gemm2_w4_ksplit(int M, int N, int K, const W4Plan& plan) {
     const int tn = wn * 64;
     const int64_t tiles = (int64_t)((M + G2M - 1) / G2M) * ((N + tn - 1) / tn);
     const int ktiles = K / G2K, Gt = plan.Gs / 2;
-    const int target = wn == 4 ? 256 : 512;  // workgroups that fill the chip
+    static int env_target = -1, env_max = -1;  // PARROT_GEMM2_W4_SPLIT_TARGET / _KSMAX (A/B)
+    if (env_target < 0) {
+        const char* e = getenv("PARROT_GEMM2_W4_SPLIT_TARGET");
+        env_target = e ? atoi(e) : 0;
+        const char* m = getenv("PARROT_GEMM2_W4_KSMAX");
+        env_max = m ? atoi(m) : 8;
+    }
+    const int target = env_target > 0 ? env_target : (wn == 4 ? 256 : 512);  // workgroups that fill the chip
     int ks = tiles >= (wn == 4 ? 128 : 192) ? 1 : (int)(target / (tiles > 0 ? tiles : 1));
-    if (ks > 8) ks = 8;
+    if (ks > env_max) ks = env_max;
     const int G_all = (ktiles + Gt - 1) / Gt;
     while (ks > 1 && (G_all / ks < 1 || ktiles / ks < 4)) --ks;  // whole groups per split, ranges need not be equal
     return ks < 1 ? 1 : ks;
