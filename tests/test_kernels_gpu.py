@@ -288,6 +288,31 @@ def test_bf16_gemm_lds_dma_kernel_tiles_splits_and_ragged_edges(M, N, K, epi):
     assert torch.all(out[M] == 7.0), "wrote past the last row"
 
 
+@pytest.mark.parametrize("kind", ["bf16", "w4"])
+def test_prompt_gemm_tile_order_covers_every_tile_exactly_once(kind):
+    """The XCD-aware workgroup -> (m tile, n tile, K split) map of gemm2.hip must be a bijection for every tile count: a sweep of
+    row / column counts (n-tile counts that are and are not multiples of 8, m-tile counts with and without small divisors, split and
+    unsplit launches) against a float64 product computed with torch on the device.  A tile computed twice is harmless, a tile never
+    computed shows up as the buffer's fill value."""
+    g = gen(40)
+    K = 128
+    for M in (129, 384, 640, 896, 1300, 2048):
+        for N in (128, 1024, 1152, 2944, 9216):
+            x = torch.randn(M, K, generator=g).to(BF).to(DEV)
+            out = torch.full((M, N), 777.0, dtype=BF, device=DEV)
+            if kind == "bf16":
+                W = (torch.randn(N, K, generator=g) * 0.05).to(BF).to(DEV)
+                ops.bf16_linear(W, x, out)
+                want = x.double() @ W.double().t()
+            else:
+                qw, s_, z_, tc, Wd = make_w4(N, K, 128, 41)
+                lin = w4_module(qw, s_, z_, N, K, 128)
+                lin.hip_linear(x, out)
+                want = x.double() @ Wd.to(DEV).t()
+            err = (out.double() - want).abs()
+            assert float(err.max()) <= 2 ** -7 * max(1.0, float(want.abs().max())), (kind, M, N, float(err.max()))
+
+
 # ------------------------------------------------------------------------------------------------ dense bf16
 @pytest.mark.parametrize("N,K", [(64, 128), (100, 768), (64, 4096), (32, 16384), (16, 3072), (8, 32768), (40, 352)])
 @pytest.mark.parametrize("M", [1, 2, 3])
