@@ -269,9 +269,10 @@ gemm_kernel(const bf16_t* __restrict__ A, int lda, int M, const void* __restrict
 __global__ void __launch_bounds__(256)
 gemm_splitk_epilogue_kernel(const float* __restrict__ part, const float* __restrict__ part2, int ksplit, int M, int N,
                             const bf16_t* __restrict__ bias, const bf16_t* residual, int ldr, bf16_t* out, int ldo, int epi) {
-    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= (int64_t)M * N) return;
-    const int row = (int)(t / N), col = (int)(t % N);
+    // one row per ceil(N / 256) workgroups (a flat element index cost a 64-bit division per element)
+    const unsigned bpr = (unsigned)(N + 255) / 256u;
+    const int row = (int)(blockIdx.x / bpr), col = (int)(blockIdx.x % bpr) * 256 + (int)threadIdx.x;
+    if (row >= M || col >= N) return;
     float a = 0.f, b = 0.f;
     for (int z = 0; z < ksplit; ++z) {
         a += part[((int64_t)z * M + row) * N + col];
@@ -351,7 +352,7 @@ static int gemm_launch(int kid, const void* Wp, const void* W2p, const void* x, 
 #undef PARROT_GEMM_GO2
     if (rc != PARROT_OK || ksplit == 1) return rc;
     const int64_t n = (int64_t)M * N;
-    return launch(K_GEMM_SPLITK, gemm_splitk_epilogue_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, (const float*)part,
+    return launch(K_GEMM_SPLITK, gemm_splitk_epilogue_kernel, dim3((unsigned)((int64_t)M * ((N + 255) / 256))), dim3(256), 0, st, (const float*)part,
                   (const float*)part2, ksplit, M, N, (const bf16_t*)bias, (const bf16_t*)residual, ldr, (bf16_t*)out, ldo, epilogue);
 }
 
@@ -419,7 +420,7 @@ int parrot_bf16_gemm(const void* W, const void* W2, const void* x, int ldx, int 
         rc = gemm2_launch(W, x, ldx, M, bias, residual, ldr, out, ldo, N, K, epilogue, (float*)workspace, (hipStream_t)stream, &ks);
         if (rc != PARROT_OK || ks == 1) return rc;
         const int64_t n = (int64_t)M * N;
-        return launch(K_GEMM_SPLITK, gemm_splitk_epilogue_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+        return launch(K_GEMM_SPLITK, gemm_splitk_epilogue_kernel, dim3((unsigned)((int64_t)M * ((N + 255) / 256))), dim3(256), 0, (hipStream_t)stream,
                       (const float*)workspace, (const float*)nullptr, ks, M, N, (const bf16_t*)bias, (const bf16_t*)residual, ldr,
                       (bf16_t*)out, ldo, epilogue);
     }
@@ -449,7 +450,7 @@ int parrot_w4_gemm(const void* packed, const void* packed2, const void* x, int l
                              &part, &part2, nullptr);
         if (rc != PARROT_OK || ks == 1) return rc;
         const int64_t mn = (int64_t)M * N;
-        return launch(K_GEMM_SPLITK, gemm_splitk_epilogue_kernel, dim3((unsigned)((mn + 255) / 256)), dim3(256), 0, st, (const float*)part,
+        return launch(K_GEMM_SPLITK, gemm_splitk_epilogue_kernel, dim3((unsigned)((int64_t)M * ((N + 255) / 256))), dim3(256), 0, st, (const float*)part,
                       (const float*)part2, ks, M, N, (const bf16_t*)bias, (const bf16_t*)residual, ldr, (bf16_t*)out, ldo, epilogue);
     }
     const int G = plan.Gs * 32;
@@ -486,7 +487,7 @@ int parrot_w4c_gemm(const void* packed, const void* packed2, const void* code16_
                          &part2, code16_bf16);
     if (rc != PARROT_OK || ks == 1) return rc;
     const int64_t mn = (int64_t)M * N;
-    return launch(K_GEMM_SPLITK, gemm_splitk_epilogue_kernel, dim3((unsigned)((mn + 255) / 256)), dim3(256), 0, st, (const float*)part,
+    return launch(K_GEMM_SPLITK, gemm_splitk_epilogue_kernel, dim3((unsigned)((int64_t)M * ((N + 255) / 256))), dim3(256), 0, st, (const float*)part,
                   (const float*)part2, ks, M, N, (const bf16_t*)bias, (const bf16_t*)residual, ldr, (bf16_t*)out, ldo, epilogue);
 }
 
