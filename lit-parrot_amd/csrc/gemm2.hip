@@ -178,7 +178,7 @@ int gemm2_ksplit(int M, int N, int K) {
         const char* e = getenv("PARROT_GEMM2_SPLIT_TARGET");
         target = e ? atoi(e) : 512;
     }
-    int ks = tiles >= 192 ? 1 : (int)(target / (tiles > 0 ? tiles : 1));
+    int ks = tiles > 256 ? 1 : (int)(target / (tiles > 0 ? tiles : 1));  // up to 256 tiles: split, two workgroups fit a CU
     if (ks > 8) ks = 8;
     while (ks > 1 && ktiles / ks < 8) --ks;  // (uneven ranges are fine: split z owns steps [z kt / ks, (z + 1) kt / ks))
     return ks < 1 ? 1 : ks;
@@ -585,7 +585,12 @@ int gemm2_w4_ksplit(int M, int N, int K, const W4Plan& plan) {
         env_max = m ? atoi(m) : 8;
     }
     const int target = env_target > 0 ? env_target : (wn == 4 ? 256 : 512);  // workgroups that fill the chip
-    int ks = tiles >= (wn == 4 ? 128 : 192) ? 1 : (int)(target / (tiles > 0 ? tiles : 1));
+    static int thr = -1;  // PARROT_GEMM2_W4_SPLIT_BELOW: launches with fewer tiles than this split K (A/B)
+    if (thr < 0) {
+        const char* e = getenv("PARROT_GEMM2_W4_SPLIT_BELOW");
+        thr = e ? atoi(e) : 257;  // 256 tiles still split two ways: two workgroups fit a CU (Falcon-40B 128-token prefill 25.8 -> 23.2 ms)
+    }
+    int ks = tiles >= (wn == 4 ? 128 : thr) ? 1 : (int)(target / (tiles > 0 ? tiles : 1));
     if (ks > env_max) ks = env_max;
     const int G_all = (ktiles + Gt - 1) / Gt;
     while (ks > 1 && (G_all / ks < 1 || ktiles / ks < 4)) --ks;  // whole groups per split, ranges need not be equal

@@ -854,7 +854,7 @@ static int w8_gemm2_ksplit(int M, int N, int K) {
         const char* e = getenv("PARROT_W8_SPLIT_TARGET");
         target = e ? atoi(e) : 512;
     }
-    int ks = tiles >= 192 ? 1 : (int)(target / (tiles > 0 ? tiles : 1));
+    int ks = tiles > 256 ? 1 : (int)(target / (tiles > 0 ? tiles : 1));  // up to 256 tiles: split, two workgroups fit a CU
     if (ks > 8) ks = 8;
     while (ks > 1 && ktiles / ks < 4) --ks;
     return ks < 1 ? 1 : ks;
