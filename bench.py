@@ -179,6 +179,7 @@ def main() -> None:
     ap.add_argument("--workload", default="llama2-7b-int4", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=20.0)
+    ap.add_argument("--engine", type=int, default=-1, help="1 / 0: force the one-launch stream engine on / off (default: the library's choice)")
     args = ap.parse_args()
 
     rank, local, world = rank_env()
@@ -199,6 +200,10 @@ def main() -> None:
     from lit_parrot_amd.generate.base import _session
     from lit_parrot_amd.synth import build_synthetic_model, synthetic_prompt
 
+    if args.engine >= 0:
+        from lit_parrot_amd.generate import base as _gb
+
+        _gb.ENGINE_DEFAULT = bool(args.engine)
     cfg_name, mode, T, dtype_label = WORKLOADS[args.workload]
     cfg = Config.from_name(cfg_name)
     total = T + args.warmup + args.steps + 1
@@ -244,6 +249,7 @@ def main() -> None:
     ctx_mean = T + args.warmup + args.steps / 2.0
     w_bytes, kv_bytes = token_bytes(cfg, mode, ctx_mean)
     kb = kernel_bytes_per_token(cfg, mode)
+    kb["eng_token"] = (w_bytes + kv_bytes, 1)  # the stream engine: the whole token is one launch
     dom = max(stats, key=lambda k: stats[k][0])
     kernels = {k: {"avg_us": v[0] / v[1] * 1e3, "launches_per_token": v[1] / prof_steps, "ms_per_token": v[0] / prof_steps}
                for k, v in sorted(stats.items(), key=lambda kv: -kv[1][0])}

@@ -11,7 +11,9 @@
  *  - plain pointers and ints only; every pointer is a DEVICE pointer unless
  *    its name ends in `_host`;
  *  - the caller owns every buffer; the library never allocates or frees
- *    tensor memory and keeps no mutable state besides the profiling sink;
+ *    tensor memory and keeps no mutable state besides the profiling sink (and, once per kernel, the LDS-size
+ *    attribute of its code object); it reads no environment variable - the A/B switches and stamp hooks behind
+ *    DESIGN.md's measurements exist only in the diagnostic build (-DPARROT_DIAG);
  *  - `stream` is a hipStream_t passed as void*; every call only enqueues work
  *    on it (no synchronisation), so a call sequence can be hipGraph-captured;
  *  - return value: 0 on success, negative PARROT_E* on failure; the message is
@@ -196,22 +198,10 @@ int parrot_attn_fused_decode(const void* qkv, const void* rope_cos, const void* 
                              const int32_t* pos, int n_groups, int q_per_kv, int hs, int S, int nsplit,
                              void* workspace, void* tickets, void* k_cache, void* v_cache, void* y,
                              void* stream);
-/* The same launch with extra workgroups that read up to four byte ranges (the packed weights of the Linears that follow:
- * out-projection, MLP) while the attention occupies only n_groups workgroups and leaves the HBM idle; nothing is written,
- * the lines stay in L2 / the memory-side cache for the next launches.  prefetch_wgs = number of extra workgroups (0 = none). */
-int parrot_attn_fused_decode_pf(const void* qkv, const void* rope_cos, const void* rope_sin, int n_elem,
-                                const int32_t* pos, int n_groups, int q_per_kv, int hs, int S, int nsplit,
-                                void* workspace, void* tickets, void* k_cache, void* v_cache, void* y,
-                                const void* const* prefetch_ptrs, const int64_t* prefetch_bytes, int n_prefetch,
-                                int prefetch_wgs, void* stream);
-
 /* ---- small ops of the step ----------------------------------------------------------
  * x[m] = wte[tokens[(pos ? *pos : 0) + m]]   (lit_gpt/model.py:99)                    */
 int parrot_embedding(const void* wte, int d, const int64_t* tokens, const int32_t* pos, int M,
                      void* out, int ldo, void* stream);
-/* Pull a read-only buffer (weights of the NEXT Linear) on chip from a side stream while the current kernel runs; no
- * dependency on it is ever needed. */
-int parrot_prefetch(const void* data, int64_t bytes, int workgroups, void* stream);
 /* greedy step of generate() (generate/base.py:136-153 with top_k=1):
  * tokens[*pos + 1] = argmax(logits) (lowest index on ties); then *pos += 1.          */
 /* ---- GPTQ quantiser, the column loop of one 128-column block (quantize/gptq.py:397-431) -------------------------
@@ -234,69 +224,74 @@ int parrot_stop_check(const int64_t* tokens, const int32_t* pos, const int32_t* 
                       const int32_t* stop_off, int n_stop, int longest, int32_t* flag, void* stream);
 int parrot_argmax_advance(const void* logits, int V, int64_t* tokens, int32_t* pos, void* stream);
 
-/* ---- persistent decode step: ONE launch per token --------------------------------------------------
- * The whole token (generate/base.py:131-153 for one iteration: embedding, every Block, ln_f, lm_head, greedy
- * sampling) is a static program of ops run by 256 resident workgroups that hand activations over through
- * write-through stores and arrival counters, so that the weight stream of op k+1 is already in flight while
- * op k's results are exchanged (csrc/persist.hip).  The caller builds the program once per model (host array of
- * parrot_pk_op_t, then copied to device memory) and calls parrot_pk_step per token; every pointer inside the
- * structs is a device pointer owned by the caller.                                                          */
-#define PARROT_PK_GEMV 0   /* int4 Linear (W4K weights) with optional norm prologue and epilogue */
-#define PARROT_PK_ATTN 1   /* split + RoPE + KV append + attention + combine (x = QKV vector, out = heads) */
-#define PARROT_PK_ARGMAX 2 /* tokens[pos+1] = argmax(logits), pos += 1 */
-#define PARROT_PK_MAX_SLABS 12
+/* ---- stream engine: ONE launch per decode token ------------------------------------------------------------
+ * The whole token (generate/base.py:131-153 for one iteration: embedding, every Block of lit_gpt/model.py:158-180,
+ * ln_f, lm_head, greedy sampling) runs as one launch of 256 workgroups, one per CU (csrc/engine.hip).  In every
+ * workgroup one LOADER wave streams that CU's share of every op's int4 weights - and of the K/V cache rows the CU
+ * attends over - through a ring of LDS slots by LDS-DMA, in a fixed order that never waits for a data dependency, only
+ * for a free slot; seven CONSUMER waves compute from LDS.  Activation vectors pass between CUs as 8-byte {data, tag}
+ * granules (tag = the step's epoch) written with write-through stores and polled with L1-bypassing loads: there is no
+ * grid barrier.  Weights are kept in the "E4" layout: per 8 output rows (a block), per 1024 input
+ * columns (a quad), four 1-KiB pieces in which lane l holds the 32-column slice of row l % 8 in quantisation group
+ * 8 * quad + l / 8, plus one metadata piece per four quads; a CU owns a contiguous range of blocks of every Linear.
+ * Supported: GPTQ int4 with group 128 and no bias, RMSNorm, sequential residual, SwiGLU MLP, head size 64 / 128,
+ * q_per_kv 1 / 2 (the Llama-2 7B family); everything else keeps the multi-launch step.                               */
+#define PARROT_ENG_GEMV 0
+#define PARROT_ENG_ATTN 1
+#define PARROT_ENG_EPI_LOGITS 4 /* lm_head: plain bf16 logits + the CU's arg-max candidate */
+#define PARROT_ENG_WGS 256
 
-typedef struct parrot_pk_slab {
-    int32_t slice0, nslices, g0, w_off16, meta_off16;
-} parrot_pk_slab_t;
-
-typedef struct parrot_pk_op {
-    int32_t type;     /* PARROT_PK_* */
-    int32_t epilogue; /* PARROT_EPI_* */
-    int32_t N, K;
-    int32_t nslabs, row16, Gs; /* W4K plan, filled by parrot_pk_fill_w4 */
-    int32_t norm_kind;         /* 0 none, 1 RMSNorm, 2 LayerNorm fused in front */
+typedef struct parrot_eng_op {
+    int32_t type;          /* PARROT_ENG_* */
+    int32_t epilogue;      /* PARROT_EPI_NONE / RESIDUAL / SWIGLU or PARROT_ENG_EPI_LOGITS */
+    int32_t K;             /* input elements (GEMV) */
+    int32_t nblocks;       /* 8-lane-row blocks of the E4 matrix: N / 8, or N / 4 for the SwiGLU pair */
+    int32_t nq;            /* quads per block = ceil(K / 1024) */
+    int32_t buf;           /* which of the two LDS activation buffers this op's input uses (consecutive GEMVs alternate) */
+    int32_t norm_kind;     /* 0 none, 1 RMSNorm fused in front */
     float norm_eps;
-    int32_t x_from_embedding;   /* the input vector is wte[tokens[pos]] (first block) */
-    int32_t res_from_embedding; /* the residual is wte[tokens[pos]] (first block) */
-    int32_t track_argmax;       /* lm_head: also record this workgroup's arg-max */
-    const void* W;              /* W4K weights; W2 = second weight of the SwiGLU epilogue or NULL */
-    const void* W2;
-    const void* x;        /* input vector: K bf16 (GEMV) / the QKV vector (ATTN) */
-    const void* norm_w;   /* K bf16 */
-    const void* norm_b;   /* K bf16 or NULL */
-    const void* bias;     /* N bf16 or NULL */
-    const void* residual; /* N bf16 or NULL */
-    void* out;            /* N bf16 */
-    void* k_cache;        /* ATTN: [n_groups][S][hs] bf16 */
+    int32_t in_embedding;  /* the input vector is wte[tokens[pos]] (QKV of the first block) */
+    int32_t res_embedding; /* the residual is wte[tokens[pos]] (out-projection of the first block) */
+    int32_t reserved0, reserved1;
+    const void* W;         /* E4 weights */
+    const void* norm_w;    /* K bf16 */
+    const uint64_t* in;    /* K / 2 input granules (GEMV), (q_per_kv + 2) * hs / 2 per group: the QKV vector (ATTN) */
+    void* out;             /* output granules; LOGITS: V bf16, plain stores */
+    uint64_t* part;        /* ATTN: n_head * nsplit * (hs + 2) fp32 granules {acc[hs], m, l} */
+    void* k_cache;         /* ATTN: [n_groups][S][hs] bf16 */
     void* v_cache;
-    parrot_pk_slab_t slab[PARROT_PK_MAX_SLABS];
-} parrot_pk_op_t;
+} parrot_eng_op_t;
 
-typedef struct parrot_pk_state {
-    const parrot_pk_op_t* ops; /* device array */
+typedef struct parrot_eng_state {
+    const parrot_eng_op_t* ops; /* device array */
     int32_t nops;
-    int32_t d; /* n_embd */
+    int32_t d;                  /* n_embd */
     int64_t* tokens;
     int32_t* pos;
+    uint32_t* epoch;            /* 1 word, starts at 1; the launch tags its granules with it and leaves epoch + 1 */
+    uint32_t* err;              /* 1 word, zero-initialised; non-zero after a bounded wait gave up */
     const void* wte;
-    const void* rope_cos;
+    const void* rope_cos;       /* fp16 [block_size][n_elem] */
     const void* rope_sin;
     int32_t n_elem, n_groups, q_per_kv, hs, S, V, rsqrt_mode;
-    int32_t lds_x_bytes; /* max over GEMV ops of 2*K, rounded up to 16 */
-    float* attn_ws;      /* parrot_attn_workspace_floats(1, n_head, hs, 256 / n_groups) */
-    uint32_t* tickets;   /* n_groups, zero-initialised */
-    uint32_t* counters;  /* 8 * 32 uint32 (8 shards on separate 128-B lines); zeroed by every parrot_pk_step */
-    uint32_t* err;       /* 1 word, zero-initialised; non-zero after a barrier timeout */
-    float* argmax_val;   /* 256 */
-    uint32_t* argmax_idx; /* 256 */
-    uint64_t* dbg;        /* NULL, or nops*8 words: 100 MHz timestamps of workgroup 0's phases (diagnostic runs only) */
-} parrot_pk_state_t;
+    int32_t nsplit;             /* CUs per query group in the attention op: min(8, 256 / n_groups) */
+    int32_t greedy;             /* 1: tokens[pos + 1] = argmax(logits), pos += 1 inside the launch */
+    int32_t lds_buf0_bytes, lds_buf1_bytes; /* from parrot_eng_lds_bytes */
+    uint64_t* arg;              /* 2 * 256 granules: every CU's arg-max candidate {value, index} */
+    uint64_t* dbg;              /* NULL, or nops * 4 words: 100 MHz stamps of workgroup 0 (diagnostic runs only) */
+} parrot_eng_state_t;
 
-/* fill N, K and the W4K plan of a GEMV op (host side); PARROT_EUNSUPPORTED if the shape does not fit the step */
-int parrot_pk_fill_w4(parrot_pk_op_t* op_host, int N, int K, int group);
-/* one token: memset of the counters + the persistent kernel, enqueued on `stream` (graph-capturable) */
-int parrot_pk_step(const parrot_pk_state_t* state_host, void* stream);
+/* bytes of the E4 image of an (N, K) int4 matrix with group 128 (dual = 1: the SwiGLU pair, N rows each) */
+int64_t parrot_e4_bytes(int N, int K, int dual);
+/* reference format (quant_weight / scales / zeros of quantize/gptq.py:216-231, group 128) -> E4; q2 / s2 / z2 = fc_2 of a
+ * SwiGLU pair or NULL */
+int parrot_e4_repack(const void* q1, const void* s1, const void* z1, const void* q2, const void* s2, const void* z2,
+                     int N, int K, void* e4, void* stream);
+/* LDS bytes of one activation buffer for inputs of up to K elements (attention scratch for hs / q_per_kv included when
+ * hs > 0); PARROT_EUNSUPPORTED when the step does not fit the CU */
+int64_t parrot_eng_lds_bytes(int K, int hs, int q_per_kv, int nsplit);
+/* one token, enqueued on `stream` (graph-capturable) */
+int parrot_eng_step(const parrot_eng_state_t* state_host, void* stream);
 
 #ifdef __cplusplus
 }

@@ -10,7 +10,7 @@ from pathlib import Path
 PKG_DIR = Path(__file__).resolve().parent
 CSRC = PKG_DIR / "csrc"
 LIB_PATH = PKG_DIR / "libparrot_hip.so"
-SOURCES = ["core.hip", "w4.hip", "dense.hip", "w8.hip", "norm.hip", "attn.hip", "attn_prefill.hip", "misc.hip", "persist.hip", "gemm.hip", "gemm2.hip", "gptq.hip"]
+SOURCES = ["core.hip", "w4.hip", "dense.hip", "w8.hip", "norm.hip", "attn.hip", "attn_prefill.hip", "misc.hip", "engine.hip", "gemm.hip", "gemm2.hip", "gptq.hip"]
 ARCH = "gfx950"
 
 
@@ -30,16 +30,19 @@ def needs_build() -> bool:
 
 
 def _compile_one(args):
-    exe, src, obj, verbose = args
+    exe, src, obj, verbose, diag = args
     cmd = [exe, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", "-Wall", "-Wno-unused-function", "-c", src, "-o", obj]
+    if diag:  # diagnostic build: environment A/B switches and the stamp / tuning hooks of tools/ (never the shipped library)
+        cmd.insert(1, "-DPARROT_DIAG")
     if verbose:
         print(" ".join(cmd))
     proc = subprocess.run(cmd, capture_output=True, text=True)
     return src, proc.returncode, proc.stdout + proc.stderr
 
 
-def build(force: bool = False, verbose: bool = False) -> Path:
-    """Build libparrot_hip.so if it is missing or older than its sources: one hipcc -c per source file, in parallel, then a link."""
+def build(force: bool = False, verbose: bool = False, diag: bool = False) -> Path:
+    """Build libparrot_hip.so if it is missing or older than its sources: one hipcc -c per source file, in parallel, then a link.
+    ``diag`` compiles with -DPARROT_DIAG (A/B switches from the environment, stamp hooks) for the measurement tools."""
     if not force and not needs_build():
         return LIB_PATH
     from concurrent.futures import ThreadPoolExecutor
@@ -48,7 +51,7 @@ def build(force: bool = False, verbose: bool = False) -> Path:
     objdir = PKG_DIR / "build"
     objdir.mkdir(exist_ok=True)
     srcs = [CSRC / s for s in SOURCES if (CSRC / s).exists()]
-    jobs = [(exe, str(src), str(objdir / (src.stem + ".o")), verbose) for src in srcs]
+    jobs = [(exe, str(src), str(objdir / (src.stem + ".o")), verbose, diag) for src in srcs]
     workers = max(1, min(len(jobs), (os.cpu_count() or 2)))
     with ThreadPoolExecutor(max_workers=workers) as pool:
         results = list(pool.map(_compile_one, jobs))
@@ -67,4 +70,6 @@ def build(force: bool = False, verbose: bool = False) -> Path:
 
 
 if __name__ == "__main__":
-    print(build(force=True, verbose=True))
+    import sys
+
+    print(build(force=True, verbose=True, diag="--diag" in sys.argv))

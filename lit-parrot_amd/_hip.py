@@ -30,35 +30,29 @@ class ParrotNorm(C.Structure):
 
 _np = C.POINTER(ParrotNorm)
 
-# ---- persistent decode step (parrot_pk_op_t / parrot_pk_state_t of include/parrot_hip.h)
-PK_GEMV, PK_ATTN, PK_ARGMAX = 0, 1, 2
-PK_MAX_SLABS = 12
-PK_WGS = 256
+# ---- stream engine (parrot_eng_op_t / parrot_eng_state_t of include/parrot_hip.h)
+ENG_GEMV, ENG_ATTN = 0, 1
+ENG_EPI_LOGITS = 4
+ENG_WGS = 256
 
 
-class PkSlab(C.Structure):
-    _fields_ = [(n, C.c_int32) for n in ("slice0", "nslices", "g0", "w_off16", "meta_off16")]
-
-
-class PkOp(C.Structure):  # parrot_pk_op_t
+class EngOp(C.Structure):  # parrot_eng_op_t
     _fields_ = (
-        [(n, C.c_int32) for n in ("type", "epilogue", "N", "K", "nslabs", "row16", "Gs", "norm_kind")]
+        [(n, C.c_int32) for n in ("type", "epilogue", "K", "nblocks", "nq", "buf", "norm_kind")]
         + [("norm_eps", C.c_float)]
-        + [(n, C.c_int32) for n in ("x_from_embedding", "res_from_embedding", "track_argmax")]
-        + [(n, C.c_void_p) for n in ("W", "W2", "x", "norm_w", "norm_b", "bias", "residual", "out", "k_cache", "v_cache")]
-        + [("slab", PkSlab * PK_MAX_SLABS)]
+        + [(n, C.c_int32) for n in ("in_embedding", "res_embedding", "reserved0", "reserved1")]
+        + [(n, C.c_void_p) for n in ("W", "norm_w", "inp", "out", "part", "k_cache", "v_cache")]
     )
 
 
-class PkState(C.Structure):  # parrot_pk_state_t
+class EngState(C.Structure):  # parrot_eng_state_t
     _fields_ = (
         [("ops", C.c_void_p), ("nops", C.c_int32), ("d", C.c_int32)]
-        + [(n, C.c_void_p) for n in ("tokens", "pos", "wte", "rope_cos", "rope_sin")]
-        + [(n, C.c_int32) for n in ("n_elem", "n_groups", "q_per_kv", "hs", "S", "V", "rsqrt_mode", "lds_x_bytes")]
-        + [(n, C.c_void_p) for n in ("attn_ws", "tickets", "counters", "err", "argmax_val", "argmax_idx", "dbg")]
+        + [(n, C.c_void_p) for n in ("tokens", "pos", "epoch", "err", "wte", "rope_cos", "rope_sin")]
+        + [(n, C.c_int32) for n in ("n_elem", "n_groups", "q_per_kv", "hs", "S", "V", "rsqrt_mode", "nsplit", "greedy",
+                                    "lds_buf0_bytes", "lds_buf1_bytes")]
+        + [(n, C.c_void_p) for n in ("arg", "dbg")]
     )
-
-
 
 
 # name -> (restype, argtypes); must list every function include/parrot_hip.h declares
@@ -92,11 +86,11 @@ SIGNATURES = {
     "parrot_attn_fused_decode": (_i, [_vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
     "parrot_attn_prefill_scratch_elems": (_i64, [_i, _i, _i]),
     "parrot_attn_prefill": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _i, _vp]),
-    "parrot_attn_fused_decode_pf": (_i, [_vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp]),
-    "parrot_pk_fill_w4": (_i, [C.POINTER(PkOp), _i, _i, _i]),
-    "parrot_pk_step": (_i, [C.POINTER(PkState), _vp]),
+    "parrot_e4_bytes": (_i64, [_i, _i, _i]),
+    "parrot_e4_repack": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp]),
+    "parrot_eng_lds_bytes": (_i64, [_i, _i, _i, _i]),
+    "parrot_eng_step": (_i, [C.POINTER(EngState), _vp]),
     "parrot_embedding": (_i, [_vp, _i, _vp, _vp, _i, _vp, _i, _vp]),
-    "parrot_prefetch": (_i, [_vp, _i64, _i, _vp]),
     "parrot_gptq_block": (_i, [_vp, _i, _i, _i, _i, _vp, _i, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
     "parrot_stop_check": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp]),
     "parrot_argmax_advance": (_i, [_vp, _i, _vp, _vp, _vp]),

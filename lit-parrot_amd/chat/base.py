@@ -58,7 +58,7 @@ class ChatSession(DecodeSession):
     """DecodeSession whose greedy step also runs the device-side stop check (captured in the same graph)."""
 
     def __init__(self, model: GPT, max_seq_length: int, max_tokens: int, greedy: bool) -> None:
-        super().__init__(model, max_seq_length, max_tokens, greedy, persistent=False)
+        super().__init__(model, max_seq_length, max_tokens, greedy, engine=False)
         self.stop = _StopState(self.device)
         self.n_stop_captured = None
 

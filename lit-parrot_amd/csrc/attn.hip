@@ -272,12 +272,11 @@ __device__ __forceinline__ void attn_stamp(unsigned long long* dbg, int i) {
     if (dbg != nullptr && threadIdx.x == 0 && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0)
         dbg[i] = __builtin_amdgcn_s_memrealtime();
 }
-static unsigned long long* g_attn_dbg_host = nullptr;
-
-struct PrefetchArgs {  // up to four byte ranges read (and dropped) by the extra workgroups of the fused decode launch
-    const void* ptr[4];
-    int64_t bytes[4];
-};
+#ifdef PARROT_DIAG
+static unsigned long long* g_attn_dbg_host = nullptr;  // diagnostic build only: set by parrot_tune_attn_stamps
+#else
+static constexpr unsigned long long* g_attn_dbg_host = nullptr;
+#endif
 
 template <int HS, int HQ, int WAVES>
 __global__ void __launch_bounds__(WAVES * 64)
@@ -285,31 +284,9 @@ attn_fused_decode_kernel(const bf16_t* __restrict__ qkv, const __half* __restric
                          const __half* __restrict__ rope_sin, int n_elem, const int32_t* __restrict__ pos_ptr,
                          bf16_t* __restrict__ k_cache, bf16_t* __restrict__ v_cache, int n_groups, int q_per_kv, int S,
                          int nsplit, float* __restrict__ ws, unsigned int* __restrict__ tickets, bf16_t* __restrict__ y,
-                         unsigned long long* dbg, PrefetchArgs pf) {
+                         unsigned long long* dbg) {
     constexpr int LPR = HS / 8;
     constexpr int RPW = 64 / LPR;
-    if (blockIdx.x >= (unsigned)n_groups) {
-        // Prefetch workgroups.  Decode attention keeps 32 of the 256 CUs busy for ~6 us with next to no HBM traffic; the extra
-        // workgroups of this launch (blockIdx.x >= n_groups) spend that time reading the weights of the Linears that follow
-        // (plain loads: the lines stay in L2 / the memory-side cache), so that those launches start on warm data.
-        if (blockIdx.y | blockIdx.z) return;
-        const int p = blockIdx.x - n_groups, P = gridDim.x - n_groups;
-        uint32_t acc = 0;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const uint4* base = reinterpret_cast<const uint4*>(pf.ptr[r]);
-            const int64_t n16 = pf.bytes[r] >> 4;
-            const int64_t per = (n16 + P - 1) / P;
-            const int64_t end = min(n16, (int64_t)(p + 1) * per);
-#pragma unroll 4
-            for (int64_t i = (int64_t)p * per + threadIdx.x; i < end; i += WAVES * 64) {
-                const uint4 v = base[i];
-                acc ^= v.x ^ v.y ^ v.z ^ v.w;
-            }
-        }
-        if (acc == 0x9E3779B9u && pf.bytes[0] < 0) y[0] = 0;  // never true: keeps the loads alive
-        return;
-    }
     attn_stamp(dbg, 0);
     __shared__ float sh_acc[HQ][WAVES][HS];  // one merged state per wave
     __shared__ float sh_m[HQ][WAVES], sh_l[HQ][WAVES];
@@ -529,16 +506,16 @@ attn_fused_decode_kernel(const bf16_t* __restrict__ qkv, const __half* __restric
 template <int HS>
 static int attn_fused_launch(const void* qkv, const void* cosp, const void* sinp, int n_elem, const int32_t* pos,
                              void* k_cache, void* v_cache, int n_groups, int q_per_kv, int S, int nsplit, void* ws,
-                             void* tickets, void* y, hipStream_t st, const PrefetchArgs& pf, int pf_wgs) {
+                             void* tickets, void* y, hipStream_t st) {
     const int hq = q_per_kv == 1 ? 1 : (q_per_kv == 2 ? 2 : 4);
     // 16 waves when a split holds more keys than 4 waves cover in two steps
     const int per = (S + nsplit - 1) / nsplit;
     const bool wide = per > 2 * kAttnWaves * (64 / (HS / 8));
-    const dim3 grid(n_groups + pf_wgs, nsplit, (q_per_kv + hq - 1) / hq), block((wide ? 16 : kAttnWaves) * 64);
+    const dim3 grid(n_groups, nsplit, (q_per_kv + hq - 1) / hq), block((wide ? 16 : kAttnWaves) * 64);
 #define PARROT_FUSED_GO(HQV, WV)                                                                                        \
     return launch(K_ATTN_FUSED, attn_fused_decode_kernel<HS, HQV, WV>, grid, block, 0, st, (const bf16_t*)qkv,          \
                   (const __half*)cosp, (const __half*)sinp, n_elem, pos, (bf16_t*)k_cache, (bf16_t*)v_cache, n_groups,   \
-                  q_per_kv, S, nsplit, (float*)ws, (unsigned int*)tickets, (bf16_t*)y, g_attn_dbg_host, pf)
+                  q_per_kv, S, nsplit, (float*)ws, (unsigned int*)tickets, (bf16_t*)y, g_attn_dbg_host)
     if (wide) {
         if (q_per_kv == 1) PARROT_FUSED_GO(1, 16);
         if (q_per_kv == 2) PARROT_FUSED_GO(2, 16);
@@ -593,15 +570,16 @@ int parrot_qkv_rope_kvappend(const void* qkv, int ldqkv, int M, const void* rope
                   n_elem, rope_local, pos, n_groups, q_per_kv, hs, S, (bf16_t*)q_out, (bf16_t*)k_cache, (bf16_t*)v_cache);
 }
 
-int parrot_tune_attn_stamps(void* dbg8_u64) {  // diagnostic: device buffer of 8 uint64, or NULL to switch off
+#ifdef PARROT_DIAG
+int parrot_tune_attn_stamps(void* dbg8_u64) {  // diagnostic build: device buffer of 8 uint64, or NULL to switch off
     g_attn_dbg_host = (unsigned long long*)dbg8_u64;
     return PARROT_OK;
 }
+#endif
 
-int parrot_attn_fused_decode_pf(const void* qkv, const void* rope_cos, const void* rope_sin, int n_elem, const int32_t* pos,
-                                int n_groups, int q_per_kv, int hs, int S, int nsplit, void* workspace, void* tickets,
-                                void* k_cache, void* v_cache, void* y, const void* const* prefetch_ptrs,
-                                const int64_t* prefetch_bytes, int n_prefetch, int prefetch_wgs, void* stream) {
+int parrot_attn_fused_decode(const void* qkv, const void* rope_cos, const void* rope_sin, int n_elem, const int32_t* pos,
+                             int n_groups, int q_per_kv, int hs, int S, int nsplit, void* workspace, void* tickets,
+                             void* k_cache, void* v_cache, void* y, void* stream) {
     PARROT_REQUIRE(qkv && pos && k_cache && v_cache && y, "attn_fused_decode: null pointer");
     PARROT_REQUIRE(n_groups >= 1 && q_per_kv >= 1 && S >= 1, "attn_fused_decode: bad shape");
     PARROT_UNSUPPORTED(q_per_kv <= kFusedMaxQ, "attn_fused_decode: at most %d query heads per group (got %d)", kFusedMaxQ, q_per_kv);
@@ -610,36 +588,15 @@ int parrot_attn_fused_decode_pf(const void* qkv, const void* rope_cos, const voi
     PARROT_REQUIRE(nsplit >= 1 && nsplit <= 65535, "attn_fused_decode: nsplit out of range");
     PARROT_REQUIRE(nsplit == 1 || (workspace && tickets), "attn_fused_decode: workspace and tickets required when nsplit > 1");
     PARROT_REQUIRE(aligned16(qkv) && aligned16(k_cache) && aligned16(v_cache), "attn_fused_decode: 16-byte alignment");
-    PARROT_REQUIRE(n_prefetch >= 0 && n_prefetch <= 4 && prefetch_wgs >= 0 && prefetch_wgs <= 4096, "attn_fused_decode: bad prefetch request");
-    PrefetchArgs pf;
-    for (int r = 0; r < 4; ++r) {
-        pf.ptr[r] = qkv;  // (a valid address for the empty ranges)
-        pf.bytes[r] = 0;
-        if (r < n_prefetch && prefetch_wgs > 0) {
-            PARROT_REQUIRE(prefetch_ptrs && prefetch_bytes && prefetch_bytes[r] >= 0, "attn_fused_decode: bad prefetch range");
-            if (prefetch_bytes[r] < 16) continue;  // empty range
-            PARROT_REQUIRE(prefetch_ptrs[r] && aligned16(prefetch_ptrs[r]), "attn_fused_decode: prefetch ranges must be 16-byte aligned device buffers");
-            pf.ptr[r] = prefetch_ptrs[r];
-            pf.bytes[r] = prefetch_bytes[r] & ~(int64_t)15;
-        }
-    }
-    const int pf_wgs = (n_prefetch > 0) ? prefetch_wgs : 0;
     hipStream_t st = (hipStream_t)stream;
     switch (hs) {
-        case 32: return attn_fused_launch<32>(qkv, rope_cos, rope_sin, n_elem, pos, k_cache, v_cache, n_groups, q_per_kv, S, nsplit, workspace, tickets, y, st, pf, pf_wgs);
-        case 64: return attn_fused_launch<64>(qkv, rope_cos, rope_sin, n_elem, pos, k_cache, v_cache, n_groups, q_per_kv, S, nsplit, workspace, tickets, y, st, pf, pf_wgs);
-        case 128: return attn_fused_launch<128>(qkv, rope_cos, rope_sin, n_elem, pos, k_cache, v_cache, n_groups, q_per_kv, S, nsplit, workspace, tickets, y, st, pf, pf_wgs);
+        case 32: return attn_fused_launch<32>(qkv, rope_cos, rope_sin, n_elem, pos, k_cache, v_cache, n_groups, q_per_kv, S, nsplit, workspace, tickets, y, st);
+        case 64: return attn_fused_launch<64>(qkv, rope_cos, rope_sin, n_elem, pos, k_cache, v_cache, n_groups, q_per_kv, S, nsplit, workspace, tickets, y, st);
+        case 128: return attn_fused_launch<128>(qkv, rope_cos, rope_sin, n_elem, pos, k_cache, v_cache, n_groups, q_per_kv, S, nsplit, workspace, tickets, y, st);
         default: break;
     }
     set_error("attn_fused_decode: head size %d not built (32, 64, 128)", hs);
     return PARROT_EUNSUPPORTED;
-}
-
-int parrot_attn_fused_decode(const void* qkv, const void* rope_cos, const void* rope_sin, int n_elem, const int32_t* pos,
-                             int n_groups, int q_per_kv, int hs, int S, int nsplit, void* workspace, void* tickets,
-                             void* k_cache, void* v_cache, void* y, void* stream) {
-    return parrot_attn_fused_decode_pf(qkv, rope_cos, rope_sin, n_elem, pos, n_groups, q_per_kv, hs, S, nsplit, workspace, tickets,
-                                       k_cache, v_cache, y, nullptr, nullptr, 0, 0, stream);
 }
 
 int64_t parrot_attn_workspace_floats(int M, int n_head, int hs, int nsplit) {

@@ -328,11 +328,7 @@ int parrot_attn_prefill(const void* q, int M, const int32_t* pos, const void* k_
     if (rc != PARROT_OK) return rc;
     const int n_head = n_groups * q_per_kv, ldq = n_head * hs;
     const dim3 grid((M + 127) / 128, n_head);
-    static int use_lds = -1;  // PARROT_ATTN_PREFILL_LDS=0: every wave streams its own K / V^T (A/B)
-    if (use_lds < 0) {
-        const char* e = getenv("PARROT_ATTN_PREFILL_LDS");
-        use_lds = e ? atoi(e) : 1;
-    }
+    const int use_lds = tune_env("PARROT_ATTN_PREFILL_LDS", 1);  // PARROT_ATTN_PREFILL_LDS=0: every wave streams its own K / V^T (A/B)
 #define PARROT_PF_LDS_GO(HSV)                                                                                                              \
     return launch(K_ATTN_PREFILL, attn_prefill_lds_kernel<HSV>, grid, dim3(256), 0, st, (const bf16_t*)q, ldq, M, pos, (const bf16_t*)k_cache, \
                   (const bf16_t*)vT_scratch, n_groups, q_per_kv, S, Spad, (bf16_t*)y, ldy)

@@ -1,0 +1,974 @@
+// Stream engine: ONE launch per decode token (include/parrot_hip.h, "stream engine").
+//
+// Reference path: one iteration of generate() (generate/base.py:131-153) = GPT.forward on one token
+// (lit_gpt/model.py:63-111): embedding, per Block (:158-180) RMSNorm -> fused QKV Linear -> RoPE + KV append + attention
+// (:194-275) -> out-projection + residual -> RMSNorm -> SwiGLU MLP (:290-301) + residual, then ln_f, lm_head, arg-max.
+//
+// Why one launch: the multi-launch step pays a ramp, a tail and a kernel boundary (~4 us in all) 161 times per token with
+// the HBM idle in between.  Here 256 workgroups (one per CU, 8 waves) stay resident for the whole token:
+//   * wave 0 is the LOADER.  It walks the CU's share of the token's byte stream - for every Linear the CU's blocks of
+//     8 output rows in the E4 layout, for every attention op the K/V rows of the CU's key range - and moves it into a
+//     ring of 7 LDS slots (17 KiB each) by LDS-DMA (global_load_lds_dwordx4, 1 KiB per wave instruction).  It never
+//     waits for a data dependency, only for a free slot, so the weights of the ops behind an activation hand-off are
+//     already on chip when the hand-off completes;
+//   * waves 1..7 are CONSUMERS.  Per op they gather the input vector into LDS (normalised, bf16), then take the op's
+//     work units round-robin as their slots land: a QUAD = 8 rows x 1024 columns (four 1-KiB pieces + one metadata
+//     word per lane) for a Linear, a K piece + V piece for attention.  Lane l of a piece holds the 32-column slice of
+//     row l % 8 in quantisation group 8 * quad + l / 8, so a lane accumulates whole groups and the only cross-lane
+//     step is one sum over the 8 lanes of a row per quad.  The wave that finishes a block's last quad sums the quads
+//     in a fixed order, applies the epilogue and publishes the 8 outputs;
+//   * activations pass between CUs as 8-byte GRANULES {data, tag}: a write-through (sc1) store by the producer, an
+//     L1-bypassing (sc1) load by the consumer, valid when tag == the launch's epoch.  No flags, no fences, no grid
+//     barrier: a consumer simply re-reads a granule until its tag matches.  Every buffer is written once per launch.
+// Every wait is bounded: on a time-out the error word is set and every later wait falls through, so the grid drains.
+#include <hip/hip_fp16.h>
+
+#include "parrot_common.h"
+#include "w4_plan.h"
+
+namespace parrot {
+
+constexpr int ENG_WGS = PARROT_ENG_WGS;
+constexpr int ENG_NC = 7;                 // consumer waves
+constexpr int ENG_THREADS = (ENG_NC + 1) * 64;
+constexpr int ENG_NSLOT = 7;              // ring slots
+constexpr int ENG_SLOT_BYTES = 17 * 1024;
+constexpr int ENG_META_OFF = 16 * 1024;   // the metadata piece of a slot, in LDS
+constexpr int ENG_MAXG = 13;              // input groups (128 elements) per consumer wave: K <= 7 * 13 * 128 = 11648
+constexpr int ENG_MAXQ = 11;              // quads per block: K <= 11264
+constexpr int ENG_RED = 16;               // block result buffers in flight
+constexpr int ENG_GROUP_STRIDE = 272;     // LDS bytes per 128-element group of an activation buffer (256 + 16: bank spread)
+constexpr int ENG_MAXFLY = 3;             // ring slots with LDS-DMA in flight (vmcnt counts at most 63 operations)
+constexpr unsigned ENG_SPINS_LDS = 2000000u;
+constexpr unsigned ENG_SPINS_GLOBAL = 60000u;
+
+typedef parrot_eng_op_t EngOp;
+typedef parrot_eng_state_t EngState;
+
+// fixed LDS area behind the ring and the two activation buffers (byte offsets inside it)
+constexpr int EF_XS = 0;                                  // [2][128] float: per-group sums of the activations
+constexpr int EF_RED = EF_XS + 2 * 128 * 4;               // [ENG_RED][ENG_MAXQ][8] float
+constexpr int EF_ROPE = EF_RED + ENG_RED * ENG_MAXQ * 8 * 4;  // [2][128] float: cos / sin row of this position
+constexpr int EF_RESID = EF_ROPE + 2 * 128 * 4;           // [64] float: the CU's own rows of the residual stream
+constexpr int EF_STAT = EF_RESID + 64 * 4;                // [8] float
+constexpr int EF_BESTV = EF_STAT + 32;                    // [8] float
+constexpr int EF_BESTI = EF_BESTV + 32;                   // [8] int
+constexpr int EF_FULL = EF_BESTI + 32;                    // [8] u32: sequence number + 1 of the slot's landed contents
+constexpr int EF_CONS = EF_FULL + 32;                     // [8] u32: units consumed from the ring slot, cumulative
+constexpr int EF_EXP = EF_CONS + 32;                      // [8] u32 (loader): units issued into the ring slot, cumulative
+constexpr int EF_NPQ = EF_EXP + 32;                       // [8] u32 (loader): pieces of the issued, unpublished slots
+constexpr int EF_DONE = EF_NPQ + 32;                      // [ENG_RED] u32: quads finished of a block
+constexpr int EF_CB = EF_DONE + ENG_RED * 4;              // consumer barrier counter
+constexpr int EF_ABORT = EF_CB + 4;
+constexpr int EF_BYTES = EF_ABORT + 12;
+
+typedef __attribute__((address_space(3))) uint32_t lds_u32_t;
+typedef const __attribute__((address_space(4))) uint32_t* cst_cu32_t;
+// the op table is constant for the launch: read it through the constant address space, so that the (wave-uniform) reads
+// are scalar loads - a vector load in the loader wave would sit in the same vmcnt queue as its LDS-DMA stream
+__device__ __forceinline__ parrot_eng_op_t eng_fetch_op(const parrot_eng_op_t* ops, int k) {
+    parrot_eng_op_t o;
+    cst_cu32_t src = (cst_cu32_t)(ops + k);
+    uint32_t* dst = reinterpret_cast<uint32_t*>(&o);
+#pragma unroll
+    for (int i = 0; i < (int)(sizeof(parrot_eng_op_t) / 4); ++i) dst[i] = src[i];
+    return o;
+}
+typedef const __attribute__((address_space(1))) uint32_t* glb_cu32_t;
+typedef const __attribute__((address_space(1))) uint16_t* glb_cu16_t;
+typedef __attribute__((address_space(1))) uint64_t glb_u64_t;
+typedef __attribute__((address_space(1))) uint32_t glb_u32_t;
+
+__device__ __forceinline__ uint32_t lds_ld(unsigned char* p) {
+    return __hip_atomic_load((lds_u32_t*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+__device__ __forceinline__ void lds_st(unsigned char* p, uint32_t v) {
+    __hip_atomic_store((lds_u32_t*)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+__device__ __forceinline__ uint32_t lds_add(unsigned char* p, uint32_t v) {
+    return __hip_atomic_fetch_add((lds_u32_t*)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+// all of this wave's LDS operations so far have completed (reads returned, writes performed)
+__device__ __forceinline__ void lds_drain() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+
+__device__ __forceinline__ void st_gran(uint64_t* p, uint32_t data, uint32_t tag) {
+    // global_store_dwordx2 ... sc1 (explicitly global, never flat: flat operations count in lgkmcnt too)
+    __hip_atomic_store((glb_u64_t*)p, (uint64_t)data | ((uint64_t)tag << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ uint64_t ld_gran(const uint64_t* p) {
+    return __hip_atomic_load((glb_u64_t*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ uint32_t ld_err(const EngState& st) {
+    return __hip_atomic_load((glb_u32_t*)st.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// ---- LDS-DMA: one wave instruction moves 64 x 16 B from per-lane global addresses to lds_dst .. lds_dst + 1023.
+// Issued from inline asm: the compiler neither counts nor waits for it; the loader counts vmcnt itself (wait_vmcnt).
+template <bool NT>
+__device__ __forceinline__ void eng_dma(const void* gsrc, unsigned lds_dst_uniform) {
+    unsigned keep;
+    if (NT)
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off nt\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(gsrc), "s"(lds_dst_uniform) : "memory");
+    else
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep) : "v"(gsrc), "s"(lds_dst_uniform) : "memory");
+}
+
+// wait until at most n of this wave's vector-memory operations are outstanding (n is wave-uniform, 0..63)
+__device__ __forceinline__ void wait_vmcnt(int n) {
+#define ENG_VM(N) case N: asm volatile("s_waitcnt vmcnt(%0)" ::"i"(N) : "memory"); break;
+#define ENG_VM4(N) ENG_VM(N) ENG_VM(N + 1) ENG_VM(N + 2) ENG_VM(N + 3)
+#define ENG_VM16(N) ENG_VM4(N) ENG_VM4(N + 4) ENG_VM4(N + 8) ENG_VM4(N + 12)
+    switch (n) {
+        ENG_VM16(0) ENG_VM16(16) ENG_VM16(32)
+        ENG_VM4(48) ENG_VM4(52) ENG_VM4(56) ENG_VM(60) ENG_VM(61) ENG_VM(62)
+        default: asm volatile("s_waitcnt vmcnt(63)" ::: "memory"); break;
+    }
+#undef ENG_VM16
+#undef ENG_VM4
+#undef ENG_VM
+}
+
+// sum over the 8 lanes that share a row (same lane % 8); every lane gets the total (DPP + gfx950 lane swaps, no LDS)
+__device__ __forceinline__ float row8_allsum(float v) {
+    v += dpp0<0x128>(v);  // row_ror:8
+    {
+        const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+        v = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+    }
+    {
+        const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+        v = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+    }
+    return v;
+}
+// attention: sum over the LPR lanes of a key row / all-reduce over the key rows of a piece (as attn.hip)
+template <int LPR>
+__device__ __forceinline__ float eng_group_sum(float v) {
+    v += dpp0<0xB1>(v);
+    v += dpp0<0x4E>(v);
+    if (LPR >= 8) v += dpp0<0x141>(v);
+    if (LPR >= 16) v += dpp0<0x128>(v);
+    return v;
+}
+template <int LPR, bool MAX>
+__device__ __forceinline__ float eng_slot_allreduce(float v) {
+    auto op = [](float a, float b) { return MAX ? fmaxf(a, b) : a + b; };
+    if (LPR <= 8) v = op(v, dpp0<0x128>(v));
+    {
+        const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+        v = op(__uint_as_float(r[0]), __uint_as_float(r[1]));
+    }
+    {
+        const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+        v = op(__uint_as_float(r[0]), __uint_as_float(r[1]));
+    }
+    return v;
+}
+
+// what every wave of the workgroup knows
+struct EngCtx {
+    unsigned char* ring;
+    unsigned char* buf0;  // the two activation buffers (no array: a run-time index would put the struct in scratch)
+    unsigned char* buf1;
+    unsigned char* fx;  // fixed area
+    uint32_t epoch;
+    int pos, cu, lane;
+    const bf16_t* emb;  // wte row of the token being decoded
+};
+
+__device__ __forceinline__ bool eng_aborted(const EngCtx& c) { return lds_ld(c.fx + EF_ABORT) != 0; }
+__device__ __forceinline__ void eng_fail(const EngState& st, const EngCtx& c, uint32_t code) {
+    lds_st(c.fx + EF_ABORT, 1u);
+    __hip_atomic_store((glb_u32_t*)st.err, code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// spin (LDS word >= target), bounded
+__device__ __forceinline__ void eng_wait_lds_ge(const EngState& st, const EngCtx& c, int off, uint32_t target, uint32_t code) {
+    unsigned spins = 0;
+    while ((int32_t)(lds_ld(c.fx + off) - target) < 0) {
+        __builtin_amdgcn_s_sleep(1);
+        if ((++spins & 63u) == 0) {
+            if (eng_aborted(c)) return;
+            if (spins > ENG_SPINS_LDS) {
+                eng_fail(st, c, code);
+                return;
+            }
+        }
+    }
+}
+
+// blocks of op that CU c owns: [b0, b1)
+__device__ __forceinline__ void eng_block_range(int nblocks, int cu, int& b0, int& b1) {
+    b0 = (int)(((int64_t)cu * nblocks) / ENG_WGS);
+    b1 = (int)(((int64_t)(cu + 1) * nblocks) / ENG_WGS);
+}
+// key range of CU c in an attention op: group g, split s; keys [kb, ke) of the n_valid admitted slots
+struct EngKeys {
+    bool part;  // this CU takes part in the attention op
+    int g, s, kb, ke, nunits;
+};
+template <int HS>
+__device__ __forceinline__ EngKeys eng_keys(const EngState& st, int cu, int pos) {
+    constexpr int KPP = 512 / HS;  // keys per 1-KiB piece
+    EngKeys k;
+    k.part = cu < st.n_groups * st.nsplit;
+    k.g = cu / st.nsplit;
+    k.s = cu % st.nsplit;
+    const int n_valid = min(pos + 1, st.S);
+    int per = (n_valid + st.nsplit - 1) / st.nsplit;
+    per = (per + KPP - 1) / KPP * KPP;
+    k.kb = min(k.s * per, n_valid);
+    k.ke = min(k.kb + per, n_valid);
+    k.nunits = k.part ? (k.ke - k.kb + KPP - 1) / KPP : 0;
+    return k;
+}
+
+// ------------------------------------------------------------------------------------------ the loader wave
+template <int HS>
+__device__ __forceinline__ void eng_loader(const EngState& st, const EngCtx& c) {
+    constexpr int KPP = 512 / HS;
+    const unsigned ring_lds = (unsigned)(uintptr_t)c.ring;
+    int seq = 0, pub = 0, inflight = 0;
+
+    auto publish_oldest = [&]() {
+        const int np = (int)lds_ld(c.fx + EF_NPQ + (pub & 7) * 4);
+        wait_vmcnt(inflight - np);
+        inflight -= np;
+        lds_st(c.fx + EF_FULL + (pub % ENG_NSLOT) * 4, (uint32_t)(pub + 1));
+        ++pub;
+    };
+    // wait for ring slot seq % NSLOT to be free; returns the cumulative unit count it had
+    auto acquire = [&](int np) -> uint32_t {
+        const int r = seq % ENG_NSLOT;
+        const uint32_t target = lds_ld(c.fx + EF_EXP + r * 4);
+        if (lds_ld(c.fx + EF_CONS + r * 4) != target) {
+            while (pub < seq) publish_oldest();  // never sleep on a free slot with landed data unannounced
+            eng_wait_lds_ge(st, c, EF_CONS + r * 4, target, 0x10000000u | (uint32_t)seq);
+        }
+        while (seq - pub >= ENG_MAXFLY || inflight + np > 60) publish_oldest();
+        return target;
+    };
+    auto commit = [&](uint32_t target, int np, int nunits) {
+        const int r = seq % ENG_NSLOT;
+        lds_st(c.fx + EF_EXP + r * 4, target + (uint32_t)nunits);
+        lds_st(c.fx + EF_NPQ + (seq & 7) * 4, (uint32_t)np);
+        inflight += np;
+        ++seq;
+    };
+
+    for (int k = 0; k < st.nops; ++k) {
+        const EngOp opv = eng_fetch_op(st.ops, k);
+        const EngOp* op = &opv;
+        if (op->type == PARROT_ENG_GEMV) {
+            int b0, b1;
+            eng_block_range(op->nblocks, c.cu, b0, b1);
+            const int nq = op->nq, spb = (nq + 3) >> 2;
+            const int64_t block_bytes = (int64_t)(4 * nq + spb) * 1024;
+            for (int b = b0; b < b1; ++b) {
+                for (int sib = 0; sib < spb; ++sib) {
+                    const int nqs = min(4, nq - 4 * sib);
+                    const int np = 4 * nqs + 1;
+                    const uint32_t target = acquire(np);
+                    const unsigned char* src = reinterpret_cast<const unsigned char*>(op->W) + (int64_t)b * block_bytes +
+                                               (int64_t)sib * ENG_SLOT_BYTES + c.lane * 16;
+                    const unsigned dst = __builtin_amdgcn_readfirstlane(ring_lds + (unsigned)((seq % ENG_NSLOT) * ENG_SLOT_BYTES));
+                    for (int j = 0; j < np - 1; ++j) eng_dma<true>(src + j * 1024, dst + (unsigned)(j * 1024));
+                    eng_dma<true>(src + (np - 1) * 1024, dst + (unsigned)ENG_META_OFF);
+                    commit(target, np, nqs);
+                }
+            }
+        } else {
+            const EngKeys ky = eng_keys<HS>(st, c.cu, c.pos);
+            const int64_t grp_bytes = (int64_t)st.S * HS * 2;
+            const unsigned char* kg = reinterpret_cast<const unsigned char*>(op->k_cache) + (int64_t)ky.g * grp_bytes;
+            const unsigned char* vg = reinterpret_cast<const unsigned char*>(op->v_cache) + (int64_t)ky.g * grp_bytes;
+            for (int u0 = 0; u0 < ky.nunits; u0 += 8) {
+                const int nu = min(8, ky.nunits - u0);
+                const uint32_t target = acquire(2 * nu);
+                const unsigned dst = __builtin_amdgcn_readfirstlane(ring_lds + (unsigned)((seq % ENG_NSLOT) * ENG_SLOT_BYTES));
+                for (int uu = 0; uu < nu; ++uu) {
+                    // rows past the group's last one are clamped to it (loaded, never used)
+                    const int64_t off = min((int64_t)(ky.kb + (u0 + uu) * KPP) * HS * 2 + c.lane * 16, grp_bytes - 16);
+                    eng_dma<false>(kg + off, dst + (unsigned)(2 * uu * 1024));
+                    eng_dma<false>(vg + off, dst + (unsigned)((2 * uu + 1) * 1024));
+                }
+                commit(target, 2 * nu, nu);
+            }
+        }
+    }
+    while (pub < seq) publish_oldest();
+}
+
+// ------------------------------------------------------------------------------------------ consumer side
+struct EngCons {
+    int cw;           // consumer wave 0..6
+    uint32_t cb_gen;  // consumer barrier generation
+    int seq;          // ring sequence number of the current op's first slot
+    int bc;           // running block count of this CU (result buffer index)
+    float best;       // lm_head: this wave's best logit so far (its epilogue lanes)
+    int best_i;
+};
+
+// barrier over the consumer waves (the loader never joins)
+__device__ __forceinline__ void eng_cbar(const EngState& st, const EngCtx& c, EngCons& w) {
+    lds_drain();
+    w.cb_gen += ENG_NC;
+    if (c.lane == 0) lds_add(c.fx + EF_CB, 1u);
+    eng_wait_lds_ge(st, c, EF_CB, w.cb_gen, 0x20000000u | w.cb_gen);
+}
+__device__ __forceinline__ void eng_wait_full(const EngState& st, const EngCtx& c, int seq) {
+    eng_wait_lds_ge(st, c, EF_FULL + (seq % ENG_NSLOT) * 4, (uint32_t)(seq + 1), 0x30000000u | (uint32_t)seq);
+}
+__device__ __forceinline__ void eng_release(const EngCtx& c, int seq) {
+    lds_drain();  // this wave's reads of the slot have returned
+    if (c.lane == 0) lds_add(c.fx + EF_CONS + (seq % ENG_NSLOT) * 4, 1u);
+}
+__device__ __forceinline__ void eng_stamp(const EngState& st, const EngCtx& c, const EngCons& w, int k, int i) {
+    if (st.dbg != nullptr && c.cu == 0 && w.cw == 0 && c.lane == 0) st.dbg[k * 4 + i] = __builtin_amdgcn_s_memrealtime();
+}
+
+// Wait until the 64 granules at p (one per lane; lanes with !need are not checked) carry this launch's tag; returns the
+// data words.  v holds the first attempt.
+__device__ __forceinline__ uint32_t eng_gran_wait(const EngState& st, const EngCtx& c, const uint64_t* p, uint64_t v, bool need,
+                                                 uint32_t code) {
+    unsigned spins = 0;
+    while (!__all(!need || (uint32_t)(v >> 32) == c.epoch)) {
+        __builtin_amdgcn_s_sleep(2);
+        if ((++spins & 15u) == 0) {
+            if (eng_aborted(c)) break;
+            if (spins > ENG_SPINS_GLOBAL || ld_err(st) != 0) {
+                eng_fail(st, c, code);
+                break;
+            }
+        }
+        v = ld_gran(p);
+    }
+    return (uint32_t)v;
+}
+
+// ---- input vector of a GEMV op -> LDS activation buffer (normalised bf16, per-group sums)
+__device__ __forceinline__ void eng_gather(const EngState& st, const EngCtx& c, EngCons& w, const EngOp* op, int k) {
+    const int K = op->K;
+    const int npairs = K >> 1;
+    const int ngr = (K + 127) >> 7;
+    const int ngr_pad = op->nq * 8;
+    unsigned char* buf = op->buf ? c.buf1 : c.buf0;
+    float* xs = reinterpret_cast<float*>(c.fx + EF_XS) + op->buf * 128;
+    uint32_t xv[ENG_MAXG], nwv[ENG_MAXG];
+    // the norm weights are constants: requested before the wait for the producers, not behind it
+    glb_cu32_t nw = (glb_cu32_t)op->norm_w;
+#pragma unroll
+    for (int i = 0; i < ENG_MAXG; ++i) {
+        const int g = w.cw + ENG_NC * i;
+        nwv[i] = 0;
+        if (op->norm_kind == 1 && g < ngr) nwv[i] = nw[min(64 * g + c.lane, npairs - 1)];
+    }
+    if (op->in_embedding) {
+        glb_cu32_t e32 = (glb_cu32_t)c.emb;
+#pragma unroll
+        for (int i = 0; i < ENG_MAXG; ++i) {
+            const int g = w.cw + ENG_NC * i;
+            xv[i] = 0;
+            if (g < ngr) {
+                const int pr = 64 * g + c.lane;
+                const uint32_t v = e32[min(pr, npairs - 1)];
+                xv[i] = pr < npairs ? v : 0u;
+            }
+        }
+    } else {
+        const uint64_t* in = op->in;
+        // poll one granule until the producers are about done, then sweep the whole share until every tag matches
+        {
+            const int pr = 64 * w.cw + c.lane;
+            if (w.cw < ngr) (void)eng_gran_wait(st, c, in + min(pr, npairs - 1), 0, pr < npairs, 0x40000000u | (uint32_t)k);
+        }
+        unsigned spins = 0;
+        for (;;) {
+            uint64_t gv[ENG_MAXG];
+#pragma unroll
+            for (int i = 0; i < ENG_MAXG; ++i) {
+                const int g = w.cw + ENG_NC * i;
+                gv[i] = (uint64_t)c.epoch << 32;
+                if (g < ngr) gv[i] = ld_gran(in + min(64 * g + c.lane, npairs - 1));
+            }
+            bool ok = true;
+#pragma unroll
+            for (int i = 0; i < ENG_MAXG; ++i) {
+                const int pr = 64 * (w.cw + ENG_NC * i) + c.lane;
+                ok = ok && ((uint32_t)(gv[i] >> 32) == c.epoch || pr >= npairs);
+                xv[i] = pr < npairs ? (uint32_t)gv[i] : 0u;
+            }
+            if (__all(ok)) break;
+            __builtin_amdgcn_s_sleep(2);
+            if ((++spins & 15u) == 0) {
+                if (eng_aborted(c)) break;
+                if (spins > ENG_SPINS_GLOBAL || ld_err(st) != 0) {
+                    eng_fail(st, c, 0x41000000u | (uint32_t)k);
+                    break;
+                }
+            }
+        }
+    }
+    float r = 1.f;
+    NormArgs na;
+    na.kind = op->norm_kind;
+    na.eps = op->norm_eps;
+    na.rsqrt_mode = st.rsqrt_mode;
+    na.d = K;
+    if (na.kind == 1) {
+        float s1 = 0.f;
+#pragma unroll
+        for (int i = 0; i < ENG_MAXG; ++i) s1 += norm_stat1(xv[i], 1);  // zero pairs add nothing
+        s1 = wave_sum_to_lane63(s1);
+        if (c.lane == 63) reinterpret_cast<float*>(c.fx + EF_STAT)[w.cw] = s1;
+        eng_cbar(st, c, w);
+        float tot = 0.f;
+        for (int i = 0; i < ENG_NC; ++i) tot += reinterpret_cast<float*>(c.fx + EF_STAT)[i];
+        r = norm_scale(na, tot);
+    }
+#pragma unroll
+    for (int i = 0; i < ENG_MAXG; ++i) {
+        const int g = w.cw + ENG_NC * i;
+        if (g < ngr_pad) {
+            uint32_t o = 0;
+            if (g < ngr) {
+                o = xv[i];
+                const int pr = 64 * g + c.lane;
+                if (na.kind == 1) o = pr < npairs ? norm_apply(o, nwv[i], 0u, 1, 0.f, r) : 0u;
+            }
+            *reinterpret_cast<uint32_t*>(buf + g * ENG_GROUP_STRIDE + c.lane * 4) = o;
+            const float t = wave_sum_to_lane63(bflo(o) + bfhi(o));
+            if (c.lane == 63) xs[g] = t;
+        }
+    }
+    eng_cbar(st, c, w);
+}
+
+// ---- one Linear: the CU's blocks, quads dealt round-robin over the consumer waves
+__device__ __forceinline__ void eng_gemv(const EngState& st, const EngCtx& c, EngCons& w, const EngOp* op, int k) {
+    eng_stamp(st, c, w, k, 0);
+    eng_gather(st, c, w, op, k);
+    eng_stamp(st, c, w, k, 1);
+    int b0, b1;
+    eng_block_range(op->nblocks, c.cu, b0, b1);
+    const int nq = op->nq, spb = (nq + 3) >> 2;
+    const unsigned char* buf = op->buf ? c.buf1 : c.buf0;
+    const float* xs = reinterpret_cast<const float*>(c.fx + EF_XS) + op->buf * 128;
+    float* red = reinterpret_cast<float*>(c.fx + EF_RED);
+    float* resid = reinterpret_cast<float*>(c.fx + EF_RESID);
+    const int r = c.lane & 7, p = c.lane >> 3;
+    const int epi = op->epilogue;
+    const int total = (b1 - b0) * nq;
+    for (int idx = w.cw; idx < total; idx += ENG_NC) {
+        const int bl = idx / nq, Q = idx - bl * nq;  // local block, quad of the row
+        const int b = b0 + bl;
+        const int sib = Q >> 2, qq = Q & 3;
+        const int seq = w.seq + bl * spb + sib;
+        eng_wait_full(st, c, seq);
+        const unsigned char* slot = c.ring + (seq % ENG_NSLOT) * ENG_SLOT_BYTES;
+        const uint32_t mt = *reinterpret_cast<const uint32_t*>(slot + ENG_META_OFF + (qq * 64 + c.lane) * 4);
+        const int G = 8 * Q + p;
+        const unsigned char* xg = buf + G * ENG_GROUP_STRIDE;
+        float acc = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const uint4 wv = *reinterpret_cast<const uint4*>(slot + (qq * 4 + i) * 1024 + c.lane * 16);
+            uint32_t xr[16];
+#pragma unroll
+            for (int q4 = 0; q4 < 4; ++q4) {
+                const uint4 xv = *reinterpret_cast<const uint4*>(xg + i * 64 + q4 * 16);
+                xr[4 * q4 + 0] = xv.x;
+                xr[4 * q4 + 1] = xv.y;
+                xr[4 * q4 + 2] = xv.z;
+                xr[4 * q4 + 3] = xv.w;
+            }
+            acc += w4_slice_dot(wv, xr);
+        }
+        float v = bflo(mt) * (acc - (128.0f + bfhi(mt)) * xs[G]);
+        v = row8_allsum(v);
+        const int rb = (w.bc + bl) % ENG_RED;
+        if (c.lane < 8) red[(rb * ENG_MAXQ + Q) * 8 + c.lane] = v;
+        eng_release(c, seq);  // (drains LDS: the partial sums above are written)
+        uint32_t t = 0;
+        if (c.lane == 0) t = lds_add(c.fx + EF_DONE + rb * 4, 1u);
+        t = __builtin_amdgcn_readfirstlane(t);
+        if ((int)t == nq - 1) {
+            // ---- this wave finished the block's last quad: fixed-order sum, epilogue, publish
+            asm volatile("" ::: "memory");  // the partial sums are read behind the counter, not speculated above it
+            lds_st(c.fx + EF_DONE + rb * 4, 0u);
+            float a = 0.f;
+            for (int q = 0; q < nq; ++q) a += red[(rb * ENG_MAXQ + q) * 8 + r];
+            float o = rbf(a);
+            if (epi == PARROT_EPI_RESIDUAL) {
+                const int lr = bl * 8 + r;  // the CU's own rows: the same blocks in every n_embd-row op
+                const float res = op->res_embedding ? bf2f(((glb_cu16_t)c.emb)[b * 8 + r]) : resid[lr & 63];
+                o = rbf(res + o);
+                if (c.lane < 8) resid[lr & 63] = o;
+            } else if (epi == PARROT_EPI_SWIGLU) {
+                const float gate = __shfl(o, (c.lane + 4) & 63, 64);  // lanes 0..3: fc_1 rows, 4..7: the same rows of fc_2
+                o = rbf(rbf(silu(o)) * gate);
+            }
+            const uint32_t ob = f2bf(o);
+            const uint32_t nb = (uint32_t)__shfl((int)ob, (c.lane + 1) & 63, 64);
+            if (epi == PARROT_ENG_EPI_LOGITS) {
+                if (c.lane < 8) {
+                    ((__attribute__((address_space(1))) bf16_t*)op->out)[b * 8 + r] = (bf16_t)ob;
+                    float lv = bf2f((bf16_t)ob);
+                    if (lv != lv) lv = -INFINITY;
+                    const int li = b * 8 + r;
+                    if (li < st.V && (w.best_i == 0x7fffffff || lv > w.best || (lv == w.best && li < w.best_i))) {
+                        w.best = lv;
+                        w.best_i = li;
+                    }
+                }
+            } else {
+                const int rows = epi == PARROT_EPI_SWIGLU ? 4 : 8;
+                if (c.lane < rows && (c.lane & 1) == 0)
+                    st_gran(reinterpret_cast<uint64_t*>(op->out) + ((b * rows + c.lane) >> 1), ob | (nb << 16), c.epoch);
+            }
+        }
+    }
+    w.seq += (b1 - b0) * spb;
+    w.bc += b1 - b0;
+    eng_stamp(st, c, w, k, 2);
+}
+
+// ---- attention op: split + RoPE + KV append + softmax(q k^T / sqrt(hs)) v over the CU's key range, partial states to the
+// group's leader CU, which merges them into the heads
+template <int HS, int HQ>
+__device__ __forceinline__ void eng_attn(const EngState& st, const EngCtx& c, EngCons& w, const EngOp* op, int k) {
+    constexpr int LPR = HS / 8, KPP = 64 / LPR, PW = HS + 2;
+    eng_stamp(st, c, w, k, 0);
+    const EngKeys ky = eng_keys<HS>(st, c.cu, c.pos);
+    if (!ky.part) {
+        eng_cbar(st, c, w);
+        return;
+    }
+    // scratch in activation buffer 0 (its last readers passed the barriers of this block's QKV gather)
+    unsigned char* sc = c.buf0;
+    uint32_t* raw = reinterpret_cast<uint32_t*>(sc);                                      // [(HQ + 2) * HS / 2] bf16 pairs
+    float* wpart = reinterpret_cast<float*>(sc + (HQ + 2) * HS * 2);                      // [NC][HQ][PW]
+    float* stage = wpart + ENG_NC * HQ * PW;                                              // [nsplit * PW]
+    const float* rope = reinterpret_cast<const float*>(c.fx + EF_ROPE);
+    const int dl = c.lane % LPR, j = c.lane / LPR;
+    const int n_elem = st.n_elem, half_n = n_elem >> 1;
+
+    // ---- the group's rows of the QKV vector
+    {
+        constexpr int NPAIR = (HQ + 2) * HS / 2, NLOAD = (NPAIR + 63) / 64;
+        const uint64_t* in = op->in + (int64_t)ky.g * NPAIR;
+        for (int t = w.cw; t < NLOAD; t += ENG_NC) {
+            const int pr = 64 * t + c.lane;
+            const uint64_t* p = in + min(pr, NPAIR - 1);
+            const uint32_t d = eng_gran_wait(st, c, p, ld_gran(p), pr < NPAIR, 0x50000000u | (uint32_t)k);
+            if (pr < NPAIR) raw[pr] = d;
+        }
+    }
+    eng_cbar(st, c, w);
+    eng_stamp(st, c, w, k, 1);
+    // this lane's 8 dims of every query head (RoPE, rounded to bf16, scaled), of the new key (RoPE) and the new value
+    const bf16_t* rawb = reinterpret_cast<const bf16_t*>(raw);
+    auto roped = [&](int row, int d) -> bf16_t {
+        const float x = bf2f(rawb[row * HS + d]);
+        if (d >= n_elem) return rawb[row * HS + d];
+        const float other = d < half_n ? -bf2f(rawb[row * HS + d + half_n]) : bf2f(rawb[row * HS + d - half_n]);
+        return f2bf(__fadd_rn(__fmul_rn(x, rope[d]), __fmul_rn(other, rope[128 + d])));
+    };
+    const float scale = 1.0f / sqrtf((float)HS);
+    float qf[HQ][8];
+    uint32_t knew[4], vnew[4];
+#pragma unroll
+    for (int e = 0; e < 8; e += 2) {
+        knew[e >> 1] = (uint32_t)roped(HQ, dl * 8 + e) | ((uint32_t)roped(HQ, dl * 8 + e + 1) << 16);
+        vnew[e >> 1] = raw[((HQ + 1) * HS + dl * 8 + e) >> 1];
+#pragma unroll
+        for (int h = 0; h < HQ; ++h) {
+            qf[h][e] = bf2f(roped(h, dl * 8 + e)) * scale;
+            qf[h][e + 1] = bf2f(roped(h, dl * 8 + e + 1)) * scale;
+        }
+    }
+    const int slot_new = c.pos % st.S;
+    if (w.cw == 0 && c.lane < LPR && slot_new >= ky.kb && slot_new < ky.ke) {  // KV append by the owner of the new slot
+        const int64_t off = ((int64_t)ky.g * st.S + slot_new) * HS + dl * 8;
+        typedef __attribute__((address_space(1))) u32x4_t* glb_u32x4_t;
+        *(glb_u32x4_t)(reinterpret_cast<bf16_t*>(op->k_cache) + off) = u32x4_t{knew[0], knew[1], knew[2], knew[3]};
+        *(glb_u32x4_t)(reinterpret_cast<bf16_t*>(op->v_cache) + off) = u32x4_t{vnew[0], vnew[1], vnew[2], vnew[3]};
+    }
+
+    float m[HQ], l[HQ], acc[HQ][8];
+#pragma unroll
+    for (int h = 0; h < HQ; ++h) {
+        m[h] = -INFINITY;
+        l[h] = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[h][e] = 0.f;
+    }
+    for (int u = w.cw; u < ky.nunits; u += ENG_NC) {
+        const int seq = w.seq + (u >> 3);
+        eng_wait_full(st, c, seq);
+        const unsigned char* slot = c.ring + (seq % ENG_NSLOT) * ENG_SLOT_BYTES + (u & 7) * 2048;
+        uint4 kv = *reinterpret_cast<const uint4*>(slot + c.lane * 16);
+        uint4 vv = *reinterpret_cast<const uint4*>(slot + 1024 + c.lane * 16);
+        const int kidx = ky.kb + u * KPP + j;
+        const bool ok = kidx < ky.ke;
+        if (kidx == slot_new) {
+            kv = make_uint4(knew[0], knew[1], knew[2], knew[3]);
+            vv = make_uint4(vnew[0], vnew[1], vnew[2], vnew[3]);
+        }
+        const uint32_t kd[4] = {kv.x, kv.y, kv.z, kv.w}, vd[4] = {vv.x, vv.y, vv.z, vv.w};
+#pragma unroll
+        for (int h = 0; h < HQ; ++h) {
+            float s = 0.f;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                s = fmaf(qf[h][2 * e], bflo(kd[e]), s);
+                s = fmaf(qf[h][2 * e + 1], bfhi(kd[e]), s);
+            }
+            s = eng_group_sum<LPR>(s);
+            if (ok) {
+                const float mn = fmaxf(m[h], s);
+                const float corr = __expf(m[h] - mn), pp = __expf(s - mn);
+                l[h] = l[h] * corr + pp;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    acc[h][2 * e] = acc[h][2 * e] * corr + pp * bflo(vd[e]);
+                    acc[h][2 * e + 1] = acc[h][2 * e + 1] * corr + pp * bfhi(vd[e]);
+                }
+                m[h] = mn;
+            }
+        }
+        eng_release(c, seq);
+    }
+    w.seq += (ky.nunits + 7) >> 3;
+    // ---- merge the key rows of the wave, then the waves of the CU
+#pragma unroll
+    for (int h = 0; h < HQ; ++h) {
+        const float M = eng_slot_allreduce<LPR, true>(m[h]);
+        const float f = (m[h] == -INFINITY) ? 0.f : __expf(m[h] - M);
+        const float L = eng_slot_allreduce<LPR, false>(l[h] * f);
+        float* wp = wpart + (w.cw * HQ + h) * PW;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float a = eng_slot_allreduce<LPR, false>(acc[h][e] * f);
+            if (c.lane < LPR) wp[dl * 8 + e] = a;
+        }
+        if (c.lane == 0) {
+            wp[HS] = M;
+            wp[HS + 1] = L;
+        }
+    }
+    eng_cbar(st, c, w);
+    if (w.cw == 0) {
+#pragma unroll
+        for (int h = 0; h < HQ; ++h) {
+            float M = -INFINITY;
+            for (int t = 0; t < ENG_NC; ++t) M = fmaxf(M, wpart[(t * HQ + h) * PW + HS]);
+            float L = 0.f, o0 = 0.f, o1 = 0.f;
+            for (int t = 0; t < ENG_NC; ++t) {
+                const float* wp = wpart + (t * HQ + h) * PW;
+                const float f = (wp[HS] == -INFINITY) ? 0.f : __expf(wp[HS] - M);
+                L += wp[HS + 1] * f;
+                o0 += wp[c.lane % HS] * f;
+                if (HS > 64) o1 += wp[(c.lane + 64) % HS] * f;
+            }
+            uint64_t* pg = op->part + ((int64_t)(ky.g * HQ + h) * st.nsplit + ky.s) * PW;
+            if (c.lane < HS) st_gran(pg + c.lane, __float_as_uint(o0), c.epoch);
+            if (HS > 64) st_gran(pg + 64 + c.lane, __float_as_uint(o1), c.epoch);
+            if (c.lane == 0) st_gran(pg + HS, __float_as_uint(M), c.epoch);
+            if (c.lane == 1) st_gran(pg + HS + 1, __float_as_uint(L), c.epoch);
+        }
+        if (ky.s == 0) {  // the group's leader merges the splits into the heads
+#pragma unroll
+            for (int h = 0; h < HQ; ++h) {
+                const int cnt = st.nsplit * PW;
+                const uint64_t* pg = op->part + (int64_t)(ky.g * HQ + h) * st.nsplit * PW;
+                for (int t0 = 0; t0 < cnt; t0 += 64) {
+                    const int i = t0 + c.lane;
+                    const uint64_t* p = pg + min(i, cnt - 1);
+                    const uint32_t d = eng_gran_wait(st, c, p, ld_gran(p), i < cnt, 0x51000000u | (uint32_t)k);
+                    if (i < cnt) stage[i] = __uint_as_float(d);
+                }
+                lds_drain();
+                float M = -INFINITY;
+                for (int s = 0; s < st.nsplit; ++s) M = fmaxf(M, stage[s * PW + HS]);
+                float L = 0.f, y0 = 0.f, y1 = 0.f;
+                const int d0 = (2 * c.lane) % HS;
+                for (int s = 0; s < st.nsplit; ++s) {
+                    const float ms = stage[s * PW + HS];
+                    const float f = (ms == -INFINITY) ? 0.f : __expf(ms - M);
+                    L += stage[s * PW + HS + 1] * f;
+                    y0 += stage[s * PW + d0] * f;
+                    y1 += stage[s * PW + d0 + 1] * f;
+                }
+                const uint32_t pk = (uint32_t)f2bf(y0 / L) | ((uint32_t)f2bf(y1 / L) << 16);
+                if (c.lane < HS / 2)
+                    st_gran(reinterpret_cast<uint64_t*>(op->out) + (((int64_t)(ky.g * HQ + h) * HS) >> 1) + c.lane, pk, c.epoch);
+                lds_drain();
+            }
+        }
+    }
+    eng_cbar(st, c, w);  // the scratch is free again (the next op's input goes into this buffer)
+    eng_stamp(st, c, w, k, 2);
+}
+
+template <int HS, int HQ>
+__device__ __forceinline__ void eng_consumer(const EngState& st, const EngCtx& c, int cw) {
+    EngCons w;
+    w.cw = cw;
+    w.cb_gen = 0;
+    w.seq = 0;
+    w.bc = 0;
+    w.best = -INFINITY;
+    w.best_i = 0x7fffffff;
+    for (int k = 0; k < st.nops; ++k) {
+        const EngOp opv = eng_fetch_op(st.ops, k);
+        const EngOp* op = &opv;
+        if (op->type == PARROT_ENG_GEMV)
+            eng_gemv(st, c, w, op, k);
+        else
+            eng_attn<HS, HQ>(st, c, w, op, k);
+    }
+    if (!st.greedy) {
+        if (c.cu == 0 && cw == 0 && c.lane == 0) st.epoch[0] = c.epoch + 1;
+        return;
+    }
+    // ---- greedy sampling: the CU's arg-max candidate -> CU 0 -> tokens[pos + 1], pos += 1
+    float bv = w.best;
+    int bi = w.best_i;
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        const float ov = __shfl_xor(bv, off, 64);
+        const int oi = __shfl_xor(bi, off, 64);
+        if (oi != 0x7fffffff && (bi == 0x7fffffff || ov > bv || (ov == bv && oi < bi))) {
+            bv = ov;
+            bi = oi;
+        }
+    }
+    if (c.lane == 0) {
+        reinterpret_cast<float*>(c.fx + EF_BESTV)[cw] = bv;
+        reinterpret_cast<int*>(c.fx + EF_BESTI)[cw] = bi;
+    }
+    eng_cbar(st, c, w);
+    if (cw != 0) return;
+    bv = -INFINITY;
+    bi = 0x7fffffff;
+    for (int t = 0; t < ENG_NC; ++t) {
+        const float ov = reinterpret_cast<float*>(c.fx + EF_BESTV)[t];
+        const int oi = reinterpret_cast<int*>(c.fx + EF_BESTI)[t];
+        if (oi != 0x7fffffff && (bi == 0x7fffffff || ov > bv || (ov == bv && oi < bi))) {
+            bv = ov;
+            bi = oi;
+        }
+    }
+    if (c.lane == 0) {
+        st_gran(st.arg + 2 * c.cu, __float_as_uint(bv), c.epoch);
+        st_gran(st.arg + 2 * c.cu + 1, (uint32_t)bi, c.epoch);
+    }
+    if (c.cu != 0) return;
+    bv = -INFINITY;
+    bi = 0x7fffffff;
+    for (int t0 = 0; t0 < 2 * ENG_WGS; t0 += 64) {  // lane parity = {value, index}; candidates t0/2 + lane/2
+        const uint64_t* p = st.arg + t0 + c.lane;
+        const uint32_t d = eng_gran_wait(st, c, p, ld_gran(p), true, 0x60000000u);
+        const uint32_t dn = (uint32_t)__shfl_xor((int)d, 1, 64);
+        const float ov = __uint_as_float((c.lane & 1) ? dn : d);
+        const int oi = (int)((c.lane & 1) ? d : dn);
+        if (oi != 0x7fffffff && (bi == 0x7fffffff || ov > bv || (ov == bv && oi < bi))) {
+            bv = ov;
+            bi = oi;
+        }
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        const float ov = __shfl_xor(bv, off, 64);
+        const int oi = __shfl_xor(bi, off, 64);
+        if (oi != 0x7fffffff && (bi == 0x7fffffff || ov > bv || (ov == bv && oi < bi))) {
+            bv = ov;
+            bi = oi;
+        }
+    }
+    if (c.lane == 0) {
+        st.tokens[c.pos + 1] = (bi == 0x7fffffff) ? 0 : bi;
+        st.pos[0] = c.pos + 1;
+        st.epoch[0] = c.epoch + 1;
+    }
+}
+
+template <int HS, int HQ>
+__global__ void __launch_bounds__(ENG_THREADS)
+eng_token_kernel(EngState st) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char eng_smem[];
+    EngCtx c;
+    c.ring = eng_smem;
+    c.buf0 = eng_smem + ENG_NSLOT * ENG_SLOT_BYTES;
+    c.buf1 = c.buf0 + st.lds_buf0_bytes;
+    c.fx = c.buf1 + st.lds_buf1_bytes;
+    c.epoch = st.epoch[0];
+    c.pos = st.pos[0];
+    c.cu = blockIdx.x;
+    c.lane = threadIdx.x & 63;
+    int64_t tok = st.tokens[c.pos];
+    if (tok < 0 || tok >= st.V) tok = 0;
+    c.emb = reinterpret_cast<const bf16_t*>(st.wte) + tok * st.d;
+    // control words and the RoPE row of this position
+    for (int i = threadIdx.x; i < (EF_BYTES - EF_STAT) / 4; i += ENG_THREADS) reinterpret_cast<uint32_t*>(c.fx + EF_STAT)[i] = 0u;
+    if ((int)threadIdx.x < 2 * st.n_elem) {
+        const int which = threadIdx.x / st.n_elem, d = threadIdx.x % st.n_elem;
+        const __half* tab = reinterpret_cast<const __half*>(which ? st.rope_sin : st.rope_cos);
+        reinterpret_cast<float*>(c.fx + EF_ROPE)[which * 128 + d] = __half2float(tab[(int64_t)c.pos * st.n_elem + d]);
+    }
+    __syncthreads();
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    if (wave == 0)
+        eng_loader<HS>(st, c);
+    else
+        eng_consumer<HS, HQ>(st, c, wave - 1);
+}
+
+// ------------------------------------------------------------------------------------------ E4 repack
+// one thread per 16-byte unit of the E4 image
+__global__ void __launch_bounds__(256)
+e4_repack_kernel(const uint8_t* __restrict__ q1, const bf16_t* __restrict__ s1, const bf16_t* __restrict__ z1,
+                 const uint8_t* __restrict__ q2, const bf16_t* __restrict__ s2, const bf16_t* __restrict__ z2, int N, int K,
+                 int nblocks, int nq, uint4* __restrict__ e4) {
+    const int spb = (nq + 3) >> 2;
+    const int block_units = (4 * nq + spb) * 64;
+    const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (tid >= (int64_t)nblocks * block_units) return;
+    const int B = (int)(tid / block_units), wb = (int)(tid % block_units);
+    const int sib = min(wb / (17 * 64), spb - 1);
+    const int rem = wb - sib * 17 * 64;
+    const int piece = rem >> 6, ln = rem & 63;
+    const int nqs = min(4, nq - 4 * sib);
+    const int ng = (K + 127) >> 7;
+    const bool dual = q2 != nullptr;
+    uint32_t dw[4] = {0, 0, 0, 0};
+    if (piece < 4 * nqs) {
+        const int qq = piece >> 2, i = piece & 3;
+        const int r = ln & 7, p = ln >> 3;
+        const int t = 4 * (8 * (4 * sib + qq) + p) + i;  // 32-column slice of the row
+        const uint8_t* q = (dual && r >= 4) ? q2 : q1;
+        const int row = dual ? B * 4 + (r & 3) : B * 8 + r;
+        if (t * 32 < K) {
+#pragma unroll
+            for (int d = 0; d < 4; ++d) {
+                uint32_t v = 0;
+#pragma unroll
+                for (int ii = 0; ii < 4; ++ii) {
+                    const uint32_t b = q[(int64_t)(t * 16 + d * 4 + ii) * N + row];
+                    v |= (b & 0xFu) << (4 * ii);
+                    v |= (b >> 4) << (16 + 4 * ii);
+                }
+                dw[d] = v;
+            }
+        }
+    } else {
+#pragma unroll
+        for (int jj = 0; jj < 4; ++jj) {
+            const int wd = ln * 4 + jj;
+            const int qq = wd >> 6, l = wd & 63;
+            const int r = l & 7, p = l >> 3;
+            const int G = 8 * (4 * sib + qq) + p;
+            const bf16_t* s = (dual && r >= 4) ? s2 : s1;
+            const bf16_t* z = (dual && r >= 4) ? z2 : z1;
+            const int row = dual ? B * 4 + (r & 3) : B * 8 + r;
+            if (qq < nqs && G < ng) dw[jj] = (uint32_t)s[(int64_t)row * ng + G] | ((uint32_t)z[(int64_t)row * ng + G] << 16);
+        }
+    }
+    e4[tid] = make_uint4(dw[0], dw[1], dw[2], dw[3]);
+}
+
+static int e4_shape(int N, int K, int dual, int* nblocks, int* nq) {
+    PARROT_REQUIRE(N > 0 && K > 0, "e4: N and K must be positive (N=%d K=%d)", N, K);
+    PARROT_UNSUPPORTED(K % 32 == 0, "e4: K=%d must be a multiple of 32", K);
+    PARROT_UNSUPPORTED(N % (dual ? 4 : 8) == 0, "e4: N=%d must be a multiple of %d", N, dual ? 4 : 8);
+    *nq = (K + 1023) / 1024;
+    PARROT_UNSUPPORTED(*nq <= ENG_MAXQ, "e4: K=%d is beyond the %d columns the stream engine is built for", K, ENG_MAXQ * 1024);
+    *nblocks = dual ? N / 4 : N / 8;
+    return PARROT_OK;
+}
+
+static int64_t eng_attn_scratch_bytes(int hs, int hq, int nsplit) {
+    return (int64_t)(hq + 2) * hs * 2 + (int64_t)(ENG_NC * hq + nsplit) * (hs + 2) * 4;
+}
+
+}  // namespace parrot
+
+using namespace parrot;
+
+extern "C" {
+
+int64_t parrot_e4_bytes(int N, int K, int dual) {
+    int nblocks, nq;
+    const int rc = e4_shape(N, K, dual, &nblocks, &nq);
+    if (rc != PARROT_OK) return rc;
+    return (int64_t)nblocks * (4 * nq + (nq + 3) / 4) * 1024;
+}
+
+int parrot_e4_repack(const void* q1, const void* s1, const void* z1, const void* q2, const void* s2, const void* z2, int N,
+                     int K, void* e4, void* stream) {
+    PARROT_REQUIRE(q1 && s1 && z1 && e4, "e4_repack: null pointer");
+    PARROT_REQUIRE((q2 != nullptr) == (s2 != nullptr) && (q2 != nullptr) == (z2 != nullptr), "e4_repack: the second matrix needs all three buffers");
+    PARROT_REQUIRE(aligned16(e4), "e4_repack: the E4 buffer must be 16-byte aligned");
+    int nblocks, nq;
+    const int rc = e4_shape(N, K, q2 != nullptr, &nblocks, &nq);
+    if (rc != PARROT_OK) return rc;
+    const int64_t units = (int64_t)nblocks * (4 * nq + (nq + 3) / 4) * 64;
+    const int64_t blocks = (units + 255) / 256;
+    PARROT_UNSUPPORTED(blocks < (1ll << 31), "e4_repack: matrix too large");
+    return launch(K_E4_REPACK, e4_repack_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const uint8_t*)q1,
+                  (const bf16_t*)s1, (const bf16_t*)z1, (const uint8_t*)q2, (const bf16_t*)s2, (const bf16_t*)z2, N, K, nblocks, nq,
+                  (uint4*)e4);
+}
+
+int64_t parrot_eng_lds_bytes(int K, int hs, int q_per_kv, int nsplit) {
+    PARROT_REQUIRE(K > 0, "eng_lds_bytes: K must be positive");
+    const int nq = (K + 1023) / 1024;
+    PARROT_UNSUPPORTED(nq <= ENG_MAXQ && nq * 8 <= ENG_NC * ENG_MAXG, "stream engine: K=%d is beyond what it is built for", K);
+    int64_t b = (int64_t)nq * 8 * ENG_GROUP_STRIDE;
+    if (hs > 0) {
+        const int64_t a = eng_attn_scratch_bytes(hs, q_per_kv, nsplit);
+        if (a > b) b = a;
+    }
+    return (b + 15) / 16 * 16;
+}
+
+int parrot_eng_step(const parrot_eng_state_t* state_host, void* stream) {
+    PARROT_REQUIRE(state_host != nullptr, "eng_step: null state");
+    EngState st = *state_host;
+    PARROT_REQUIRE(st.ops && st.nops >= 1 && st.tokens && st.pos && st.epoch && st.err && st.wte && st.rope_cos && st.rope_sin && st.arg,
+                   "eng_step: null pointer in state");
+    PARROT_UNSUPPORTED(st.hs == 64 || st.hs == 128, "stream engine: head size %d not built (64, 128)", st.hs);
+    PARROT_UNSUPPORTED(st.q_per_kv == 1 || st.q_per_kv == 2, "stream engine: q_per_kv=%d not built (1, 2)", st.q_per_kv);
+    PARROT_REQUIRE(st.n_groups >= 1 && st.nsplit >= 1 && st.nsplit <= 8 && st.n_groups * st.nsplit <= ENG_WGS,
+                   "eng_step: n_groups * nsplit must fit the %d workgroups", ENG_WGS);
+    PARROT_REQUIRE(st.n_elem % 2 == 0 && st.n_elem >= 0 && st.n_elem <= st.hs && st.n_elem <= 128, "eng_step: bad n_elem");
+    PARROT_REQUIRE(st.S >= 1 && st.V >= 1 && st.d >= 1, "eng_step: bad S / V / d");
+    PARROT_REQUIRE(st.lds_buf0_bytes > 0 && st.lds_buf0_bytes % 16 == 0 && st.lds_buf1_bytes > 0 && st.lds_buf1_bytes % 16 == 0,
+                   "eng_step: LDS buffer sizes must be positive multiples of 16");
+    PARROT_REQUIRE(st.lds_buf0_bytes >= eng_attn_scratch_bytes(st.hs, st.q_per_kv, st.nsplit), "eng_step: LDS buffer 0 smaller than the attention scratch");
+    const size_t lds = (size_t)ENG_NSLOT * ENG_SLOT_BYTES + st.lds_buf0_bytes + st.lds_buf1_bytes + EF_BYTES;
+    PARROT_UNSUPPORTED(lds <= 160 * 1024, "stream engine: needs %zu B of LDS", lds);
+    hipStream_t s = (hipStream_t)stream;
+#define PARROT_ENG_GO(HSV, HQV)                                                                                          \
+    do {                                                                                                                 \
+        static bool attr_set = false;                                                                                    \
+        if (!attr_set) {                                                                                                 \
+            hipError_t e = hipFuncSetAttribute((const void*)eng_token_kernel<HSV, HQV>,                                  \
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                 \
+            if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute");                                               \
+            attr_set = true;                                                                                             \
+        }                                                                                                                \
+        return launch(K_ENG_TOKEN, eng_token_kernel<HSV, HQV>, dim3(ENG_WGS), dim3(ENG_THREADS), lds, s, st);            \
+    } while (0)
+    if (st.hs == 128) {
+        if (st.q_per_kv == 1) PARROT_ENG_GO(128, 1);
+        PARROT_ENG_GO(128, 2);
+    }
+    if (st.q_per_kv == 1) PARROT_ENG_GO(64, 1);
+    PARROT_ENG_GO(64, 2);
+#undef PARROT_ENG_GO
+}
+
+}  // extern "C"

@@ -288,22 +288,14 @@ gemm_splitk_epilogue_kernel(const float* __restrict__ part, const float* __restr
 
 // 128 x 128 tiles only when they alone give the chip >= 2 workgroups per CU; otherwise 64 x 64 (4x the workgroups)
 static bool gemm_big_tiles(int M, int N) {
-    static int env = -1;  // PARROT_GEMM_BIG_MIN: minimum number of 128 x 128 tiles for the big-tile kernel (experiment hook)
-    if (env < 0) {
-        const char* e = getenv("PARROT_GEMM_BIG_MIN");
-        env = e ? atoi(e) : 512;
-    }
+    const int env = tune_env("PARROT_GEMM_BIG_MIN", 512);  // PARROT_GEMM_BIG_MIN: minimum number of 128 x 128 tiles for the big-tile kernel (experiment hook)
     return (int64_t)((M + 127) / 128) * ((N + 127) / 128) >= env;
 }
 
 // K splits for launches with too few tiles to fill the chip (short prompts): equal ranges of whole quantisation groups,
 // at least 8 K-tiles each, at most 8 splits, aiming at >= ~1536 workgroups
 static int gemm_ksplit(int M, int N, int K, int gs_tiles) {
-    static int env = -1;  // PARROT_GEMM_KSPLIT: 0 = never split (A/B), n = force
-    if (env < 0) {
-        const char* e = getenv("PARROT_GEMM_KSPLIT");
-        env = e ? atoi(e) : -2;
-    }
+    const int env = tune_env("PARROT_GEMM_KSPLIT", -2);  // PARROT_GEMM_KSPLIT: 0 = never split (A/B), n = force
     if (env == 0) return 1;
     const int64_t tiles = gemm_big_tiles(M, N) ? (int64_t)((M + 127) / 128) * ((N + 127) / 128) : (int64_t)((M + 63) / 64) * ((N + 63) / 64);
     const int ktiles = K / GBK;

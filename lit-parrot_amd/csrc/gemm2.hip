@@ -173,11 +173,7 @@ gemm2_kernel(const bf16_t* __restrict__ A, int lda, int M, const bf16_t* __restr
 int gemm2_ksplit(int M, int N, int K) {
     const int64_t tiles = (int64_t)((M + G2M - 1) / G2M) * ((N + G2N - 1) / G2N);
     const int ktiles = K / G2K;
-    static int target = -1;  // PARROT_GEMM2_SPLIT_TARGET: workgroups to aim at when splitting (two fit on a CU: 512 fill the chip)
-    if (target < 0) {
-        const char* e = getenv("PARROT_GEMM2_SPLIT_TARGET");
-        target = e ? atoi(e) : 512;
-    }
+    const int target = tune_env("PARROT_GEMM2_SPLIT_TARGET", 512);  // PARROT_GEMM2_SPLIT_TARGET: workgroups to aim at when splitting (two fit on a CU: 512 fill the chip)
     int ks = tiles > 256 ? 1 : (int)(target / (tiles > 0 ? tiles : 1));  // up to 256 tiles: split, two workgroups fit a CU
     if (ks > 8) ks = 8;
     while (ks > 1 && ktiles / ks < 8) --ks;  // (uneven ranges are fine: split z owns steps [z kt / ks, (z + 1) kt / ks))
@@ -185,11 +181,7 @@ int gemm2_ksplit(int M, int N, int K) {
 }
 
 bool gemm2_enabled() {
-    static int env = -1;  // PARROT_GEMM2=0: A/B against the first-generation kernel
-    if (env < 0) {
-        const char* e = getenv("PARROT_GEMM2");
-        env = e ? atoi(e) : 1;
-    }
+    const int env = tune_env("PARROT_GEMM2", 1);  // PARROT_GEMM2=0: A/B against the first-generation kernel
     return env != 0;
 }
 
@@ -201,11 +193,7 @@ static int g2_largest_divisor_le(int n, int cap) {
 
 int gemm2_launch(const void* W, const void* x, int ldx, int M, const void* bias, const void* residual, int ldr, void* out, int ldo,
                  int N, int K, int epilogue, float* part, hipStream_t st, int* ksplit_out) {
-    static int nbuf_env = -1;  // PARROT_GEMM2_NBUF = 2 | 3 (A/B)
-    if (nbuf_env < 0) {
-        const char* e = getenv("PARROT_GEMM2_NBUF");
-        nbuf_env = e ? atoi(e) : 0;
-    }
+    const int nbuf_env = tune_env("PARROT_GEMM2_NBUF", 0);  // PARROT_GEMM2_NBUF = 2 | 3 (A/B)
     const int ks = gemm2_ksplit(M, N, K);
     *ksplit_out = ks;
     PARROT_REQUIRE(ks == 1 || part != nullptr, "bf16_gemm: this shape splits K %d ways and needs the workspace of parrot_gemm_workspace_floats", ks);
@@ -561,11 +549,7 @@ bool gemm2_w4_takes(const W4Plan& plan, int K) {
 
 // tile shape of the int4 kernel (wave columns)
 int gemm2_w4_wn(int M) {
-    static int env = -1;  // PARROT_GEMM2_W4_WN = 2 | 4 (A/B)
-    if (env < 0) {
-        const char* e = getenv("PARROT_GEMM2_W4_WN");
-        env = e ? atoi(e) : 0;
-    }
+    const int env = tune_env("PARROT_GEMM2_W4_WN", 0);  // PARROT_GEMM2_W4_WN = 2 | 4 (A/B)
     (void)M;
     // measured (Llama-2-7B int4, 128- and 32-token prompts, uneven split-K): WN = 2 3.97 / 3.80 ms, WN = 4 4.77 / 4.33 ms - the wide
     // shape does not pay; it stays selectable for A/B
@@ -577,19 +561,10 @@ int gemm2_w4_ksplit(int M, int N, int K, const W4Plan& plan) {
     const int tn = wn * 64;
     const int64_t tiles = (int64_t)((M + G2M - 1) / G2M) * ((N + tn - 1) / tn);
     const int ktiles = K / G2K, Gt = plan.Gs / 2;
-    static int env_target = -1, env_max = -1;  // PARROT_GEMM2_W4_SPLIT_TARGET / _KSMAX (A/B)
-    if (env_target < 0) {
-        const char* e = getenv("PARROT_GEMM2_W4_SPLIT_TARGET");
-        env_target = e ? atoi(e) : 0;
-        const char* m = getenv("PARROT_GEMM2_W4_KSMAX");
-        env_max = m ? atoi(m) : 8;
-    }
+    const int env_target = tune_env("PARROT_GEMM2_W4_SPLIT_TARGET", 0), env_max = tune_env("PARROT_GEMM2_W4_KSMAX", 8);  // (A/B)
     const int target = env_target > 0 ? env_target : (wn == 4 ? 256 : 512);  // workgroups that fill the chip
-    static int thr = -1;  // PARROT_GEMM2_W4_SPLIT_BELOW: launches with fewer tiles than this split K (A/B)
-    if (thr < 0) {
-        const char* e = getenv("PARROT_GEMM2_W4_SPLIT_BELOW");
-        thr = e ? atoi(e) : 257;  // 256 tiles still split two ways: two workgroups fit a CU (Falcon-40B 128-token prefill 25.8 -> 23.2 ms)
-    }
+    // launches with fewer tiles than this split K; 256 tiles still split two ways: two workgroups fit a CU (Falcon-40B 128-token prefill 25.8 -> 23.2 ms)
+    const int thr = tune_env("PARROT_GEMM2_W4_SPLIT_BELOW", 257);
     int ks = tiles >= (wn == 4 ? 128 : thr) ? 1 : (int)(target / (tiles > 0 ? tiles : 1));
     if (ks > env_max) ks = env_max;
     const int G_all = (ktiles + Gt - 1) / Gt;

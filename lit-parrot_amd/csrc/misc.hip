@@ -116,23 +116,6 @@ stop_check_kernel(const int64_t* __restrict__ tokens, const int32_t* __restrict_
     }
 }
 
-// Touch a read-only buffer so that its lines are on chip (Infinity Cache / L2) when the kernel that needs them starts.
-// Launched on a side stream next to the kernel that precedes the consumer: it keeps the HBM busy during that kernel's
-// dispatch, arithmetic and tail phases.  Pure prefetch: nothing depends on it and it writes nothing (the conditional
-// store below can never fire; it only keeps the loads alive).
-__global__ void __launch_bounds__(256)
-prefetch_kernel(const uint4* __restrict__ p, int64_t n16, unsigned int* sink) {
-    unsigned int acc = 0;
-    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    for (; i + 3 * stride < n16; i += 4 * stride) {
-        const uint4 a = p[i], b = p[i + stride], c = p[i + 2 * stride], d = p[i + 3 * stride];
-        acc ^= a.x ^ b.y ^ c.z ^ d.w;
-    }
-    for (; i < n16; i += stride) acc ^= p[i].x;
-    if (acc == 0x9e3779b9u && sink != nullptr && blockIdx.x == 0x7fffffff) *sink = acc;
-}
-
 }  // namespace parrot
 
 using namespace parrot;
@@ -148,15 +131,6 @@ int parrot_embedding(const void* wte, int d, const int64_t* tokens, const int32_
     const int d16 = d / 8;
     return launch(K_EMBEDDING, embedding_kernel, dim3((d16 + 255) / 256, M), dim3(256), 0, (hipStream_t)stream,
                   (const uint4*)wte, d16, tokens, pos, (uint4*)out, ldo / 8);
-}
-
-int parrot_prefetch(const void* data, int64_t bytes, int workgroups, void* stream) {
-    PARROT_REQUIRE(data != nullptr && bytes >= 0 && aligned16(data), "prefetch: need a 16-byte aligned buffer");
-    if (bytes < 16) return PARROT_OK;
-    if (workgroups < 1) workgroups = 256;
-    if (workgroups > 4096) workgroups = 4096;
-    return launch(K_PREFETCH, prefetch_kernel, dim3(workgroups), dim3(256), 0, (hipStream_t)stream, (const uint4*)data,
-                  bytes / 16, (unsigned int*)nullptr);
 }
 
 int parrot_stop_check(const int64_t* tokens, const int32_t* pos, const int32_t* first_gen, const int64_t* stop_flat,

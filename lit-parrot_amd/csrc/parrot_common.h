@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include <vector>
 
 #include "../../include/parrot_hip.h"
@@ -28,6 +29,17 @@ int hip_fail(hipError_t e, const char* what);
             return PARROT_EUNSUPPORTED;           \
         }                                         \
     } while (0)
+
+// The A/B switches behind the measurements of DESIGN.md exist only in a diagnostic build (hipcc -DPARROT_DIAG, `python
+// lit-parrot_amd/_build.py --diag`): the shipped library reads no environment variable and keeps no tuning state.
+#ifdef PARROT_DIAG
+inline int tune_env(const char* name, int dflt) {
+    const char* e = getenv(name);
+    return e ? atoi(e) : dflt;
+}
+#else
+inline int tune_env(const char*, int dflt) { return dflt; }
+#endif
 
 inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
@@ -65,8 +77,8 @@ enum KernelId : int {
     K_W4_GEMM,
     K_BF16_GEMM,
     K_ATTN_FUSED,
-    K_PK_TOKEN,
-    K_PREFETCH,
+    K_ENG_TOKEN,
+    K_E4_REPACK,
     K_STOP_CHECK,
     K_GPTQ_BLOCK,
     K_W4C_GEMV,

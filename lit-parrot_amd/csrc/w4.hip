@@ -104,7 +104,11 @@ __device__ __forceinline__ void w4_stamp(unsigned long long* dbg, int i) {
         dbg[b * 8 + i] = __builtin_amdgcn_s_memrealtime();
     }
 }
-static unsigned long long* g_w4_dbg_host = nullptr;  // set by parrot_tune_w4_stamps
+#ifdef PARROT_DIAG
+static unsigned long long* g_w4_dbg_host = nullptr;  // diagnostic build only: set by parrot_tune_w4_stamps
+#else
+static constexpr unsigned long long* g_w4_dbg_host = nullptr;
+#endif
 
 // Workgroup shape: nslabs x wps waves.  Wave (slab c, j) streams slab c of row group j: RU consecutive rows.  The
 // activations (and the optional norm of them) are prepared ONCE per workgroup and shared by its row groups and by the
@@ -399,188 +403,16 @@ w4_gemv_kernel(const uint4* __restrict__ W, const uint4* __restrict__ W2, const 
     w4_stamp(dbg, 4);
 }
 
-// ------------------------------------------------------------------------------------------ streaming GEMV (M = 1)
-// The burst kernel above issues every load of the launch at once: the whole matrix is in flight, the data comes back in
-// request order per CU, and only then do the dot products run - 2-3 us of VALU work that nothing overlaps (measured with
-// in-kernel stamps).  This kernel is the decode-path replacement: about one workgroup per CU, each wave walks SEVERAL
-// row groups with a two-deep register pipeline (the loads of group i+2 are requested before group i is consumed), so the
-// HBM stream runs under the arithmetic, and the activation / norm prologue is paid once per workgroup under the first loads.
-//   workgroup b owns row groups b, b + G, b + 2G, ...; its t-th group goes to wave column j = t % wps in batch t / wps;
-//   the nslabs waves of a column split K; per batch one barrier: slab partials -> LDS (double-buffered) -> epilogue.
-template <bool DUAL, int RU, int MAXW>
-__global__ void __launch_bounds__(MAXW * 64)
-w4_stream_kernel(const uint4* __restrict__ W, const uint4* __restrict__ W2, const bf16_t* __restrict__ x,
-                 const bf16_t* __restrict__ bias, const bf16_t* residual, bf16_t* out, int N, int K, int wps, int epi,
-                 NormArgs na, W4Plan plan) {
-    constexpr int NW = DUAL ? 2 : 1;
-    extern __shared__ __attribute__((aligned(16))) unsigned char w4_smem[];  // normalised activations [K] bf16 (norm only)
-    __shared__ float red[2][MAXW][RU * NW];
-    __shared__ float stat[16];
-
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int nwaves = plan.nslabs * wps;
-    const int slab = wave / wps, j = wave % wps;
-    const W4Slab sl = plan.slab[slab];
-    const bool active = lane < sl.nslices;
-    const int lslice = active ? lane : sl.nslices - 1;
-    const int gslice = sl.slice0 + lslice;
-    const int gl = gslice / plan.Gs - sl.g0;
-    const int64_t row16 = plan.row16;
-    const int G = gridDim.x;
-    const int ngroups = (N + RU - 1) / RU;
-    const int T = ((int)blockIdx.x < ngroups) ? (ngroups - (int)blockIdx.x + G - 1) / G : 0;  // groups of this workgroup
-    const int batches = (T + wps - 1) / wps;
-
-    // ---- small L2-resident operands first (vmcnt retires in order), then the first two batches of weights
-    uint32_t xr[16];
-    const int nthreads = nwaves * 64;
-    const int chunks = K >> 3;
-    constexpr int kMaxChunkIt = 4;
-    uint4 cx[kMaxChunkIt], cw[kMaxChunkIt], cb[kMaxChunkIt];
-    if (na.kind == 0) {
-        const uint4* xp = reinterpret_cast<const uint4*>(x + (int64_t)gslice * 32);
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            uint4 v = xp[q];
-            if (!active) v = make_uint4(0, 0, 0, 0);
-            xr[4 * q + 0] = v.x; xr[4 * q + 1] = v.y; xr[4 * q + 2] = v.z; xr[4 * q + 3] = v.w;
-        }
-    } else {
-#pragma unroll
-        for (int it = 0; it < kMaxChunkIt; ++it) {
-            const int c = threadIdx.x + it * nthreads;
-            const int cc = c < chunks ? c : chunks - 1;
-            cw[it] = reinterpret_cast<const uint4*>(na.weight)[cc];
-            cb[it] = make_uint4(0, 0, 0, 0);
-            if (na.kind == 2 && na.bias != nullptr) cb[it] = reinterpret_cast<const uint4*>(na.bias)[cc];
-            cx[it] = reinterpret_cast<const uint4*>(x)[cc];
-            if (c >= chunks) cx[it] = make_uint4(0, 0, 0, 0);
-        }
-    }
-
-    uint4 w[2][NW][RU];
-    uint32_t mt[2][NW][RU];
-    // rows of batch `bi` of this wave: group t = bi * wps + j of the workgroup, i.e. global group blockIdx + t * G
-#define W4S_LOAD(BUF, BI)                                                                              \
-    {                                                                                                  \
-        const int t_ = (BI) * wps + j;                                                                 \
-        const int r0_ = ((int)blockIdx.x + min(t_, T - 1) * G) * RU;                                   \
-        _Pragma("unroll") for (int u = 0; u < RU; ++u) {                                               \
-            const int64_t row = min(r0_ + u, N - 1);                                                   \
-            const uint4* rec = W + row * row16;                                                        \
-            w[BUF][0][u] = load_nt16(rec + sl.w_off16 + lslice);                                       \
-            mt[BUF][0][u] = load_nt4(reinterpret_cast<const uint32_t*>(rec + sl.meta_off16) + gl);     \
-            if (DUAL) {                                                                                \
-                const uint4* rec2 = W2 + row * row16;                                                  \
-                w[BUF][1][u] = load_nt16(rec2 + sl.w_off16 + lslice);                                  \
-                mt[BUF][1][u] = load_nt4(reinterpret_cast<const uint32_t*>(rec2 + sl.meta_off16) + gl); \
-            }                                                                                          \
-        }                                                                                              \
-    }
-    if (batches > 0) W4S_LOAD(0, 0)
-    if (batches > 1) W4S_LOAD(1, 1)
-
-    if (na.kind != 0) {  // fused RMSNorm / LayerNorm, once per workgroup, through LDS
-        uint4* xn = reinterpret_cast<uint4*>(w4_smem);
-        float s1 = 0.f;
-#pragma unroll
-        for (int it = 0; it < kMaxChunkIt; ++it) {
-            const uint32_t dw[4] = {cx[it].x, cx[it].y, cx[it].z, cx[it].w};
-#pragma unroll
-            for (int i = 0; i < 4; ++i) s1 += norm_stat1(dw[i], na.kind);
-        }
-        s1 = block_sum_waves(s1, stat, nwaves);
-        float mean = 0.f, r;
-        if (na.kind == 2) {
-            mean = s1 / (float)na.d;
-            float s2 = 0.f;
-#pragma unroll
-            for (int it = 0; it < kMaxChunkIt; ++it) {
-                if (threadIdx.x + it * nthreads < chunks) {
-                    const uint32_t dw[4] = {cx[it].x, cx[it].y, cx[it].z, cx[it].w};
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) s2 += norm_stat2(dw[i], mean);
-                }
-            }
-            r = norm_scale(na, block_sum_waves(s2, stat, nwaves));
-        } else {
-            r = norm_scale(na, s1);
-        }
-#pragma unroll
-        for (int it = 0; it < kMaxChunkIt; ++it) {
-            const int c = threadIdx.x + it * nthreads;
-            if (c < chunks) {
-                const uint32_t dx[4] = {cx[it].x, cx[it].y, cx[it].z, cx[it].w};
-                const uint32_t dwt[4] = {cw[it].x, cw[it].y, cw[it].z, cw[it].w};
-                const uint32_t dbs[4] = {cb[it].x, cb[it].y, cb[it].z, cb[it].w};
-                uint32_t o[4];
-#pragma unroll
-                for (int i = 0; i < 4; ++i) o[i] = norm_apply(dx[i], dwt[i], dbs[i], na.kind, mean, r);
-                xn[c] = make_uint4(o[0], o[1], o[2], o[3]);
-            }
-        }
-        __syncthreads();
-        const uint4* xl = xn + (int64_t)gslice * 4;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            uint4 v = xl[q];
-            if (!active) v = make_uint4(0, 0, 0, 0);
-            xr[4 * q + 0] = v.x; xr[4 * q + 1] = v.y; xr[4 * q + 2] = v.z; xr[4 * q + 3] = v.w;
-        }
-    }
-    float xs = 0.f;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) xs += bflo(xr[i]) + bfhi(xr[i]);
-
-    // one pipeline step: consume buffer BUF (batch BI), refill it with batch BI + 2, barrier, epilogue of batch BI
-#define W4S_STEP(BUF, BI)                                                                                          \
-    {                                                                                                              \
-        _Pragma("unroll") for (int u = 0; u < RU; ++u) {                                                           \
-            _Pragma("unroll") for (int q = 0; q < NW; ++q) {                                                       \
-                const float s_ = bflo(mt[BUF][q][u]);                                                              \
-                const float zz_ = 128.0f + bfhi(mt[BUF][q][u]);                                                    \
-                const float p_ = w4_slice_dot(w[BUF][q][u], xr);                                                   \
-                const float v_ = wave_sum_to_lane63(s_ * (p_ - zz_ * xs));                                         \
-                if (lane == 63) red[(BI) & 1][wave][u * NW + q] = v_;                                              \
-            }                                                                                                      \
-        }                                                                                                          \
-        if ((BI) + 2 < batches) W4S_LOAD(BUF, (BI) + 2)                                                            \
-        __syncthreads();                                                                                           \
-        if ((int)threadIdx.x < wps * RU) {                                                                         \
-            const int jj = threadIdx.x / RU, u = threadIdx.x % RU;                                                 \
-            const int t_ = (BI) * wps + jj;                                                                        \
-            const int col = ((int)blockIdx.x + t_ * G) * RU + u;                                                   \
-            if (t_ < T && col < N) {                                                                               \
-                float a0 = 0.f, a1 = 0.f;                                                                          \
-                for (int c = 0; c < plan.nslabs; ++c) {                                                            \
-                    a0 += red[(BI) & 1][c * wps + jj][u * NW];                                                     \
-                    if (DUAL) a1 += red[(BI) & 1][c * wps + jj][u * NW + 1];                                       \
-                }                                                                                                  \
-                out[col] = apply_epilogue(epi, a0, a1, bias, residual, col);                                       \
-            }                                                                                                      \
-        }                                                                                                          \
-    }
-    for (int bi = 0; bi < batches; bi += 2) {
-        W4S_STEP(0, bi)
-        if (bi + 1 < batches) W4S_STEP(1, bi + 1)
-    }
-#undef W4S_STEP
-#undef W4S_LOAD
-}
-
-static int g_stream_wgs_per_cu_x2 = 0;  // tuning hook: workgroups per 128 CUs ... (0 = heuristic)
-
-static int g_resident_override = 0;  // tuning hook: workgroups per launch before a workgroup walks several batches
-static int g_wps_override = 0;  // tuning hook (tools/microbench.py): row groups per workgroup, 0 = heuristic
+#ifdef PARROT_DIAG  // tuning hooks of the diagnostic build (tools/microbench.py)
+static int g_resident_override = 0;  // workgroups per launch before a workgroup walks several batches
+static int g_wps_override = 0;       // row groups per workgroup, 0 = heuristic
+#else
+static constexpr int g_resident_override = 0, g_wps_override = 0;
+#endif
 
 // row groups per workgroup: aim at ~640 workgroups per launch, bounded by the waves the build allows
 static int pick_wps(int N, int RU, int nslabs, int maxw, bool norm) {
-    static int env_wps = -1;  // PARROT_W4_WPS: experiment hook
-    if (env_wps < 0) {
-        const char* e = getenv("PARROT_W4_WPS");
-        env_wps = e ? atoi(e) : 0;
-    }
+    const int env_wps = tune_env("PARROT_W4_WPS", 0);  // experiment hook
     if (env_wps > 0 && g_wps_override == 0) {
         int w = env_wps;
         if (w * nslabs > maxw) w = maxw / nslabs;
@@ -622,41 +454,10 @@ static int w4_gemv_launch_v(const void* packed, const void* packed2, const void*
                   (const uint32_t*)code);
 }
 
-static int g_use_stream = 0;  // the pipelined kernel measured no faster than the burst kernel (tools/microbench.py); kept selectable
-
-template <bool DUAL, int RU, int MAXW>
-static int w4_stream_launch(const void* packed, const void* packed2, const void* x, const void* bias, const void* residual,
-                            void* out, int N, int K, int epi, const NormArgs& na, const W4Plan& plan, hipStream_t st) {
-    int wps = MAXW / plan.nslabs;
-    if (wps > 2) wps = 2;  // 2 wave columns per workgroup (4 waves at K = 4096, 6 at K = 11008 with wps 1)
-    if (g_wps_override > 0 && g_wps_override * plan.nslabs <= MAXW) wps = g_wps_override;
-    if (wps < 1) wps = 1;
-    const int ngroups = (N + RU - 1) / RU;
-    int G = g_stream_wgs_per_cu_x2 > 0 ? 128 * g_stream_wgs_per_cu_x2 : 256;  // ~ one workgroup per CU
-    if (G * wps > ngroups) G = (ngroups + wps - 1) / wps;
-    const int nthreads = 64 * plan.nslabs * wps;
-    size_t lds = 0;
-    if (na.kind != 0) {
-        PARROT_UNSUPPORTED((K >> 3) <= 4 * nthreads, "w4_gemv: fused norm needs K <= %d with this workgroup shape", 32 * nthreads);
-        lds = (size_t)K * 2;
-    }
-    return launch(DUAL ? K_W4_GEMV_DUAL : K_W4_GEMV, w4_stream_kernel<DUAL, RU, MAXW>, dim3(G), dim3(nthreads), lds, st,
-                  (const uint4*)packed, (const uint4*)packed2, (const bf16_t*)x, (const bf16_t*)bias, (const bf16_t*)residual,
-                  (bf16_t*)out, N, K, wps, epi, na, plan);
-}
-
 template <int M, bool CB>
 static int w4_gemv_launch(const void* packed, const void* packed2, const void* x, int ldx, const void* bias,
                           const void* residual, int ldr, void* out, int ldo, int N, int K, int epi, const NormArgs& na,
                           const W4Plan& plan, hipStream_t st, const void* code) {
-    if (M == 1 && g_use_stream && !CB) {
-        const bool dual = epi == PARROT_EPI_SWIGLU;
-        if (plan.nslabs <= 8)
-            return dual ? w4_stream_launch<true, 4, 8>(packed, packed2, x, bias, residual, out, N, K, epi, na, plan, st)
-                        : w4_stream_launch<false, 8, 8>(packed, packed2, x, bias, residual, out, N, K, epi, na, plan, st);
-        return dual ? w4_stream_launch<true, 2, 16>(packed, packed2, x, bias, residual, out, N, K, epi, na, plan, st)
-                    : w4_stream_launch<false, 4, 16>(packed, packed2, x, bias, residual, out, N, K, epi, na, plan, st);
-    }
     // rows in flight per wave: 8 for the single-row decode kernel, fewer when a second weight or more rows share the registers
     constexpr int RU1 = (M == 1) ? 8 : 4;  // (16 / 8 rows in flight measured slower: occupancy drops to 3 waves per SIMD)
     // (codebook weights: the 32 raw lookups of a slice live beside the weights: 8 x 2 rows would take 168 VGPRs, 3 waves per SIMD)
@@ -743,27 +544,20 @@ using namespace parrot;
 
 extern "C" {
 
-// tuning hook, not part of the public header: rows of output per workgroup (0 = heuristic)
-int parrot_tune_w4_stamps(void* dbg24_u64) {  // diagnostic: device buffer of 24 uint64, or NULL to switch off
+#ifdef PARROT_DIAG  // diagnostic build: tuning / stamp hooks, not part of the public header
+int parrot_tune_w4_stamps(void* dbg24_u64) {  // device buffer of 24 uint64, or NULL to switch off
     g_w4_dbg_host = (unsigned long long*)dbg24_u64;
     return PARROT_OK;
 }
-
-int parrot_tune_w4_stream(int use_stream, int wgs_per_128_cus) {  // diagnostic / tuning
-    g_use_stream = use_stream;
-    g_stream_wgs_per_cu_x2 = wgs_per_128_cus;
-    return PARROT_OK;
-}
-
 int parrot_tune_w4_resident(int workgroups) {  // 0 = derive from the workgroup shape
     g_resident_override = workgroups > 0 ? workgroups : 0;
     return PARROT_OK;
 }
-
 int parrot_tune_w4_rows_per_wg(int wps) {  // (name kept) row groups per workgroup, 0 = heuristic
     g_wps_override = (wps >= 1 && wps <= 8) ? wps : 0;
     return PARROT_OK;
 }
+#endif
 
 int64_t parrot_w4_packed_bytes(int N, int K, int group) {
     W4Plan plan;

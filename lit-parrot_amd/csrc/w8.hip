@@ -849,11 +849,7 @@ w8_dequant_epilogue_kernel(const int32_t* __restrict__ part, const int32_t* __re
 static int w8_gemm2_ksplit(int M, int N, int K) {
     const int64_t tiles = (int64_t)((M + 127) / 128) * ((N + 127) / 128);
     const int ktiles = K / 128;
-    static int target = -1;  // PARROT_W8_SPLIT_TARGET: workgroups to aim at when splitting K
-    if (target < 0) {
-        const char* e = getenv("PARROT_W8_SPLIT_TARGET");
-        target = e ? atoi(e) : 512;
-    }
+    const int target = tune_env("PARROT_W8_SPLIT_TARGET", 512);  // PARROT_W8_SPLIT_TARGET: workgroups to aim at when splitting K
     int ks = tiles > 256 ? 1 : (int)(target / (tiles > 0 ? tiles : 1));  // up to 256 tiles: split, two workgroups fit a CU
     if (ks > 8) ks = 8;
     while (ks > 1 && ktiles / ks < 4) --ks;

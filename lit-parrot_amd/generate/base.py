@@ -30,7 +30,7 @@ class DecodeSession:
     """Static buffers + captured graph of the single-token step for one (model, max_seq_length, greedy) choice."""
 
     def __init__(self, model: GPT, max_seq_length: int, max_tokens: int, greedy: bool, use_graph: bool = True,
-                 persistent: Optional[bool] = None) -> None:
+                 engine: Optional[bool] = None) -> None:
         self.model, self.S, self.greedy = model, max_seq_length, greedy
         dev = model.transformer.wte.weight.device
         if dev.type != "cuda":
@@ -46,20 +46,20 @@ class DecodeSession:
         if not model.kv_caches or model.kv_caches[0][0].size(2) != max_seq_length or model.kv_caches[0][0].size(0) != 1:
             model.kv_caches = model.build_kv_caches(self.tokens.view(1, -1), max_seq_length, model.rope_cache[0].size(-1))
         self.caches = [(k[0], v[0]) for k, v in model.kv_caches]
-        # one launch per token when the model fits the persistent step (int4 everywhere, ...), else 5 launches per block
-        from ..persist import PersistentStep
+        # one launch per token when the model fits the stream engine (csrc/engine.hip), else 5 launches per block
+        from ..engine import StreamEngine
 
-        self.pk = None
-        if persistent is None:
-            persistent = PERSISTENT_DEFAULT
-        if persistent and PersistentStep.supported(model) is None:
-            self.pk = PersistentStep(model, self.tokens, self.pos, self.caches, max_seq_length, greedy)
+        self.eng = None
+        if engine is None:
+            engine = ENGINE_DEFAULT
+        if engine and StreamEngine.supported(model) is None:
+            self.eng = StreamEngine(model, self.tokens, self.pos, self.caches, max_seq_length, greedy)
 
 
     # one decode step = the launch sequence that gets captured
     def _step(self) -> None:
-        if self.pk is not None:
-            self.pk.step()  # embedding .. lm_head (.. arg-max + advance when greedy) in one launch
+        if self.eng is not None:
+            self.eng.step()  # embedding .. lm_head (.. arg-max + advance when greedy) in one launch
             return
         logits = self.model.run_rows(self.ws, self.tokens, self.pos, self.pos, self.S, self.caches, self.model.rope_cache)
         if self.greedy:
@@ -106,10 +106,10 @@ class DecodeSession:
             self.graph.replay()
         else:
             self._step()
-        return self.pk.logits[0] if self.pk is not None else self.ws.logits[0]
+        return self.eng.logits[0] if self.eng is not None else self.ws.logits[0]
 
 
-PERSISTENT_DEFAULT = False  # experimental: correct, but its per-op software barrier is still slower than kernel boundaries
+ENGINE_DEFAULT = False  # the one-launch stream engine for the models it is built for (Llama-2 7B family, int4 g128)
 
 
 def _session(model: GPT, max_seq_length: int, max_tokens: int, greedy: bool) -> DecodeSession:

@@ -36,23 +36,8 @@ from .rmsnorm import RMSNorm
 
 # parallel-residual blocks: overlap the MLP up-projection with the attention branch (M = 1); PARROT_PARALLEL_BRANCHES=0 disables
 PARALLEL_BRANCHES = os.environ.get("PARROT_PARALLEL_BRANCHES", "1") != "0"
-# Decode attention leaves the HBM idle (32 busy workgroups, ~3 MB of K/V): extra workgroups of the same launch read the
-# weights of the Linears that follow.  0 = off, 1 = out-projection, 2 = + MLP up-projection(s), 3 = + MLP down-projection.
-ATTN_PREFETCH = int(os.environ.get("PARROT_ATTN_PREFETCH", "0"))
-ATTN_PREFETCH_WGS = int(os.environ.get("PARROT_ATTN_PREFETCH_WGS", "224"))
 ATTN_PREFILL_MFMA = os.environ.get("PARROT_ATTN_PREFILL_MFMA", "1") != "0"  # prompts from position 0: parrot_attn_prefill
 
-
-def _streamed_weight(mod: nn.Module) -> Optional[torch.Tensor]:
-    """The device buffer a Linear's decode kernel streams (kernel-native packed weights for the 4-bit classes)."""
-    if hasattr(mod, "packed"):
-        return mod.packed()
-    w = getattr(mod, "weight", None)
-    return w.data if w is not None and w.is_cuda else None
-
-# decode step of sequential-residual models: pull the NEXT Linear's weights on chip from a side stream while the current
-# kernel runs (PARROT_PREFETCH=0 disables; =N limits each prefetch to N MiB)
-WEIGHT_PREFETCH = os.environ.get("PARROT_PREFETCH", "0")
 
 RoPECache = Tuple[torch.Tensor, torch.Tensor]
 KVCache = Tuple[torch.Tensor, torch.Tensor]
@@ -88,52 +73,6 @@ class Workspace:
         return self._attn_ws[nsplit]
 
 
-class WeightPrefetcher:
-    """Side-stream prefetch of the weights of the Linear that runs AFTER the one being launched.
-
-    The decode step is a dependency chain of weight-streaming kernels; between two of them the HBM idles for the
-    dispatch, arithmetic and tail phases (~4-5 us).  Each Linear launch is therefore preceded by a tiny read-only
-    kernel on a side stream (gated on the previous kernel's completion) that touches the next Linear's weights, so that
-    they come from the Infinity Cache when their kernel starts.  Nothing depends on the prefetch: it cannot change results.
-    """
-
-    def __init__(self, model: "GPT", device, limit_bytes: Optional[int]) -> None:
-        self.side = torch.cuda.Stream(device=device)
-        self.limit = limit_bytes
-        launches = []
-        for block in model.transformer.h:
-            launches.append([block.attn.attn])
-            launches.append([block.attn.proj])
-            mlp = block.mlp
-            launches.append([mlp.fc_1, mlp.fc_2] if hasattr(mlp, "fc_1") else [mlp.fc])
-            launches.append([mlp.proj])
-        launches.append([model.lm_head])
-        self.index = {id(group[0]): i for i, group in enumerate(launches)}
-        self.tensors = [[self._weight(m) for m in group] for group in launches]
-
-    @staticmethod
-    def _weight(mod: nn.Module) -> torch.Tensor:
-        if hasattr(mod, "packed"):
-            return mod.packed()
-        return mod.weight.data
-
-    def before(self, mod: nn.Module) -> None:
-        i = self.index.get(id(mod))
-        if i is None:
-            return
-        main = torch.cuda.current_stream(self.side.device)
-        self.side.wait_stream(main)  # the kernel before `mod` has finished: the prefetch runs beside `mod`'s kernel
-        with torch.cuda.stream(self.side):
-            for t in self.tensors[(i + 1) % len(self.tensors)]:
-                ops.prefetch(t, 256, self.limit)
-
-    def join(self) -> None:
-        torch.cuda.current_stream(self.side.device).wait_stream(self.side)
-
-
-_ACTIVE_PREFETCHER: Optional[WeightPrefetcher] = None
-
-
 def _fused_norm(mod: Optional[nn.Module]) -> Optional[ops.Norm]:
     """Describe a norm module so that the following Linear applies it to its input rows on the fly."""
     if mod is None:
@@ -163,8 +102,6 @@ def _linear(mod: nn.Module, x: torch.Tensor, out: torch.Tensor, *, epilogue: int
             if m is not None and id(m) in LINEAR_OBSERVERS:
                 LINEAR_OBSERVERS[id(m)](x)
     norm = _fused_norm(norm)
-    if _ACTIVE_PREFETCHER is not None and x.shape[0] == 1:
-        _ACTIVE_PREFETCHER.before(mod)
     if hasattr(mod, "hip_linear"):
         return mod.hip_linear(x, out, epilogue=epilogue, residual=residual, partner=partner, norm=norm)
     if isinstance(mod, nn.Linear):
@@ -262,24 +199,13 @@ class GPT(nn.Module):
         ``pos`` (device int32[1]) is the position of row 0; ``caches[i]`` are (n_groups, S, hs) views.  Returns
         ``ws.logits``: all rows, or only the last row when the workspace was built with ``lm_rows == 1``.
         """
-        global _ACTIVE_PREFETCHER
         M = ws.M
         ops.embedding(self.transformer.wte.weight.data, tokens, tok_pos, M, ws.x)
         nsplit = ops.attn_nsplit(self.config.n_query_groups, S, self.config.q_per_kv, M)
-        use_pf = M == 1 and WEIGHT_PREFETCH != "0" and not self.config.parallel_residual
-        if use_pf and getattr(self, "_prefetcher", None) is None:
-            lim = int(WEIGHT_PREFETCH) * (1 << 20) if WEIGHT_PREFETCH.isdigit() and int(WEIGHT_PREFETCH) > 1 else None
-            self._prefetcher = WeightPrefetcher(self, ws.x.device, lim)
-        _ACTIVE_PREFETCHER = self._prefetcher if use_pf else None
-        try:
-            for block, (kc, vc) in zip(self.transformer.h, caches):
-                block.run_rows(ws, pos, S, kc, vc, rope, nsplit, rope_local)
-            last = ws.x if ws.lm_rows == M else ws.x[M - 1:M]
-            logits = _linear(self.lm_head, last, ws.logits, norm=self.transformer.ln_f)  # ln_f fused into lm_head
-            if _ACTIVE_PREFETCHER is not None:
-                _ACTIVE_PREFETCHER.join()
-        finally:
-            _ACTIVE_PREFETCHER = None
+        for block, (kc, vc) in zip(self.transformer.h, caches):
+            block.run_rows(ws, pos, S, kc, vc, rope, nsplit, rope_local)
+        last = ws.x if ws.lm_rows == M else ws.x[M - 1:M]
+        logits = _linear(self.lm_head, last, ws.logits, norm=self.transformer.ln_f)  # ln_f fused into lm_head
         return logits
 
     def forward(self, idx: torch.Tensor, max_seq_length: Optional[int] = None,
@@ -367,8 +293,7 @@ class Block(nn.Module):
                     "No checkpoint amongst the ones we support uses this configuration"
                     " (non-parallel residual and shared attention norm)."
                 )
-            self.attn.run_rows(ws, ws.x, pos, S, k_cache, v_cache, rope, nsplit, rope_local, norm=self.norm_1,
-                               upcoming=self.mlp.streamed_modules(ATTN_PREFETCH))  # -> ws.y
+            self.attn.run_rows(ws, ws.x, pos, S, k_cache, v_cache, rope, nsplit, rope_local, norm=self.norm_1)  # -> ws.y
             _linear(self.attn.proj, ws.y, ws.x, epilogue=EPI_RESIDUAL, residual=ws.x)  # x = x + h
             self.mlp.run_rows(ws, ws.x, residual=ws.x, out=ws.x, norm=self.norm_2)  # x = x + mlp(norm_2(x))
 
@@ -407,20 +332,15 @@ class CausalSelfAttention(nn.Module):
 
     def run_rows(self, ws: Workspace, x: torch.Tensor, pos: torch.Tensor, S: int, k_cache: torch.Tensor,
                  v_cache: torch.Tensor, rope: RoPECache, nsplit: int, rope_local: bool = False,
-                 norm: Optional[nn.Module] = None, upcoming: Tuple[nn.Module, ...] = ()) -> torch.Tensor:
+                 norm: Optional[nn.Module] = None) -> torch.Tensor:
         """(norm +) qkv linear, split + RoPE + cache append, attention over the cache; leaves the heads in ``ws.y``
         (the output projection is fused with the residual add by the caller).  A single new token takes the fused
         kernel (one launch); several rows (prefill) take rope_kvappend + attn_decode over all rows."""
         c = self.config
         _linear(self.attn, x, ws.qkv, norm=norm)
         if ws.M == 1 and not rope_local and c.q_per_kv <= ops.FUSED_ATTN_MAX_Q_PER_KV:
-            prefetch = None
-            if ATTN_PREFETCH > 0:
-                mods = (self.proj,) + tuple(upcoming)
-                prefetch = [t for t in (_streamed_weight(m) for m in mods) if t is not None][:4]
             return ops.attn_fused_decode(ws.qkv, rope[0], rope[1], c.rope_n_elem, pos, k_cache, v_cache, c.n_query_groups,
-                                         c.q_per_kv, c.head_size, S, nsplit, ws.attn_ws(c, nsplit), ws.tickets, ws.y,
-                                         prefetch=prefetch, prefetch_wgs=ATTN_PREFETCH_WGS)
+                                         c.q_per_kv, c.head_size, S, nsplit, ws.attn_ws(c, nsplit), ws.tickets, ws.y)
         ops.rope_kvappend(ws.qkv, rope[0], rope[1], c.rope_n_elem, pos, c.n_query_groups, c.q_per_kv, c.head_size, S,
                           ws.q, k_cache, v_cache, rope_local)
         if (ATTN_PREFILL_MFMA and getattr(ws, "pos_is_zero", False) and ops.ATTN_PREFILL_MIN_ROWS <= ws.M <= S
@@ -466,9 +386,6 @@ class GptNeoxMLP(nn.Module):
         self.run_up(ws, x, norm=norm)
         return self.run_down(ws, residual=residual, out=out)
 
-    def streamed_modules(self, level: int) -> Tuple[nn.Module, ...]:
-        return ((self.fc,) if level >= 2 else ()) + ((self.proj,) if level >= 3 else ())
-
     def run_up(self, ws, x: torch.Tensor, *, norm: Optional[nn.Module] = None) -> torch.Tensor:
         return _linear(self.fc, x, ws.h, epilogue=EPI_GELU, norm=norm)  # exact-erf GELU fused (model.py:284-287)
 
@@ -492,9 +409,6 @@ class LLaMAMLP(nn.Module):
                  norm: Optional[nn.Module] = None) -> torch.Tensor:
         self.run_up(ws, x, norm=norm)
         return self.run_down(ws, residual=residual, out=out)
-
-    def streamed_modules(self, level: int) -> Tuple[nn.Module, ...]:
-        return ((self.fc_1, self.fc_2) if level >= 2 else ()) + ((self.proj,) if level >= 3 else ())
 
     def run_up(self, ws, x: torch.Tensor, *, norm: Optional[nn.Module] = None) -> torch.Tensor:
         return _linear(self.fc_1, x, ws.h, epilogue=EPI_SWIGLU, partner=self.fc_2, norm=norm)  # silu(fc_1 x) * fc_2 x (model.py:297-301)

@@ -318,22 +318,12 @@ ATTN_PREFILL_MIN_ROWS = int(os.environ.get("PARROT_ATTN_PREFILL_MIN_ROWS", "160"
 
 def attn_fused_decode(qkv: torch.Tensor, cos: torch.Tensor, sin: torch.Tensor, n_elem: int, pos: torch.Tensor,
                       k_cache: torch.Tensor, v_cache: torch.Tensor, n_groups: int, q_per_kv: int, hs: int, S: int,
-                      nsplit: int, workspace: torch.Tensor, tickets: torch.Tensor, y: torch.Tensor,
-                      prefetch=None, prefetch_wgs: int = 0) -> torch.Tensor:
-    """Single new token: split + RoPE + KV append + attention + combine in one launch.  ``prefetch``: up to four device
-    tensors (weights of the Linears that follow) that ``prefetch_wgs`` extra workgroups read while the attention runs."""
+                      nsplit: int, workspace: torch.Tensor, tickets: torch.Tensor, y: torch.Tensor) -> torch.Tensor:
+    """Single new token: split + RoPE + KV append + attention + combine in one launch."""
     _rows(qkv, "attn_fused_decode"), _rows(y, "attn_fused_decode")
     if qkv.shape[0] != 1 or tickets.dtype != torch.int32 or tickets.numel() < n_groups * q_per_kv:
         raise ParrotHipError("attn_fused_decode: one row, int32 tickets[n_groups] expected")
     lib = _hip.load()
-    if prefetch and prefetch_wgs > 0:
-        n = len(prefetch)
-        ptrs = (C.c_void_p * n)(*[t.data_ptr() for t in prefetch])
-        sizes = (C.c_int64 * n)(*[t.numel() * t.element_size() for t in prefetch])
-        check(lib.parrot_attn_fused_decode_pf(ptr(qkv), ptr(cos), ptr(sin), n_elem, ptr(pos), n_groups, q_per_kv, hs, S,
-                                              nsplit, ptr(workspace), ptr(tickets), ptr(k_cache), ptr(v_cache), ptr(y),
-                                              ptrs, sizes, n, prefetch_wgs, stream()), "parrot_attn_fused_decode_pf")
-        return y
     check(lib.parrot_attn_fused_decode(ptr(qkv), ptr(cos), ptr(sin), n_elem, ptr(pos), n_groups, q_per_kv, hs, S,
                                        nsplit, ptr(workspace), ptr(tickets), ptr(k_cache), ptr(v_cache), ptr(y),
                                        stream()), "parrot_attn_fused_decode")
@@ -366,9 +356,3 @@ def stop_check(tokens: torch.Tensor, pos: torch.Tensor, first_gen: torch.Tensor,
         raise ParrotHipError("stop_check: tokens / stop_flat int64; pos, first_gen, stop_off, flag int32")
     check(_hip.load().parrot_stop_check(ptr(tokens), ptr(pos), ptr(first_gen), ptr(stop_flat), ptr(stop_off), n_stop, longest,
                                         ptr(flag), stream()), "parrot_stop_check")
-
-
-def prefetch(t: torch.Tensor, workgroups: int = 256, nbytes: Optional[int] = None) -> None:
-    """Enqueue (on the current stream) a read of ``t`` that leaves its lines in the on-chip caches."""
-    n = t.numel() * t.element_size() if nbytes is None else min(nbytes, t.numel() * t.element_size())
-    check(_hip.load().parrot_prefetch(ptr(t), n, workgroups, stream()), "parrot_prefetch")

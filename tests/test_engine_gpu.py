@@ -1,0 +1,212 @@
+"""The stream engine (csrc/engine.hip: one launch per decode token) against the multi-launch step and the oracle."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+import lit_parrot_amd as L  # noqa: E402
+from lit_parrot_amd import _hip  # noqa: E402
+from lit_parrot_amd.config import Config  # noqa: E402
+from lit_parrot_amd.engine import StreamEngine, e4_image  # noqa: E402
+from lit_parrot_amd.generate import base as gb  # noqa: E402
+from lit_parrot_amd.quantize.gptq import ColBlockQuantizedLinear, pack_nibbles  # noqa: E402
+from lit_parrot_amd.synth import is_linear_key, synthetic_prompt, synthetic_state_dict  # noqa: E402
+from oracle import int4 as o4  # noqa: E402
+from oracle import model as om  # noqa: E402
+
+DEV = torch.device("cuda", 0)
+BF = torch.bfloat16
+
+
+@pytest.fixture(autouse=True)
+def cpu_rsqrt_mode():
+    """Compare against the CPU oracle with the CPU-run reference's rsqrt rounding."""
+    from lit_parrot_amd import ops
+
+    ops.RMSNORM_RSQRT_MODE = 1
+    yield
+    ops.RMSNORM_RSQRT_MODE = 0
+
+
+# ------------------------------------------------------------------------------------------------ E4 layout
+def e4_expected(q: np.ndarray, s: np.ndarray, z: np.ndarray, q2=None, s2=None, z2=None) -> np.ndarray:
+    """The E4 image as include/parrot_hip.h defines it, built element by element (independent of the repack kernel):
+    q (N, K) nibbles, s / z (N, groups) uint16 bf16 bit patterns."""
+    N, K = q.shape
+    dual = q2 is not None
+    nq = (K + 1023) // 1024
+    spb = (nq + 3) // 4
+    ng = (K + 127) // 128
+    nblocks = N // 4 if dual else N // 8
+    out = np.zeros((nblocks, (4 * nq + spb) * 1024), dtype=np.uint8)
+    for B in range(nblocks):
+        base = 0
+        for sib in range(spb):
+            nqs = min(4, nq - 4 * sib)
+            for qq in range(nqs):
+                for i in range(4):
+                    for lane in range(64):
+                        r, p = lane & 7, lane >> 3
+                        t = 4 * (8 * (4 * sib + qq) + p) + i
+                        if t * 32 >= K:
+                            continue
+                        src, row = (q, B * 8 + r) if not dual else ((q if r < 4 else q2), B * 4 + (r & 3))
+                        k = src[row, t * 32:(t + 1) * 32].astype(np.uint32)
+                        dws = []
+                        for d in range(4):
+                            v = 0
+                            for ii in range(4):
+                                v |= int(k[8 * d + 2 * ii]) << (4 * ii)
+                                v |= int(k[8 * d + 2 * ii + 1]) << (16 + 4 * ii)
+                            dws.append(v)
+                        off = base + (qq * 4 + i) * 1024 + lane * 16
+                        out[B, off:off + 16] = np.frombuffer(np.array(dws, dtype=np.uint32).tobytes(), dtype=np.uint8)
+            meta = base + nqs * 4 * 1024
+            for qq in range(nqs):
+                for lane in range(64):
+                    r, p = lane & 7, lane >> 3
+                    G = 8 * (4 * sib + qq) + p
+                    if G >= ng:
+                        continue
+                    ss, zz, row = (s, z, B * 8 + r) if not dual else ((s if r < 4 else s2), (z if r < 4 else z2), B * 4 + (r & 3))
+                    w = int(ss[row, G]) | (int(zz[row, G]) << 16)
+                    off = meta + (qq * 64 + lane) * 4
+                    out[B, off:off + 4] = np.frombuffer(np.uint32(w).tobytes(), dtype=np.uint8)
+            base += (nqs * 4 + 1) * 1024
+    return out.reshape(-1)
+
+
+def make_linear(N, K, seed):
+    g = torch.Generator().manual_seed(seed)
+    lin = ColBlockQuantizedLinear(K, N, False, tile_cols=128)
+    q = torch.randint(0, 16, (N, K), generator=g, dtype=torch.uint8)
+    ng = (K + 127) // 128
+    s = (torch.rand(N, ng, generator=g) * 0.01 + 0.001).to(BF)
+    z = torch.randint(0, 16, (N, ng), generator=g).to(BF)
+    lin.quant_weight.copy_(pack_nibbles(q))
+    lin.scales = s.clone()
+    lin.zeros = z.clone()
+    return lin.to(DEV), q.numpy(), s.view(torch.int16).numpy().view(np.uint16), z.view(torch.int16).numpy().view(np.uint16)
+
+
+@pytest.mark.parametrize("N,K", [(16, 128), (24, 352), (8, 1024), (16, 2080 - 32), (8, 4096), (8, 5120)])
+def test_e4_repack_is_the_layout_the_header_defines(N, K):
+    lin, q, s, z = make_linear(N, K, 11)
+    got = e4_image(lin).cpu().numpy()
+    want = e4_expected(q, s, z)
+    assert got.shape == want.shape and np.array_equal(got, want)
+    lin2, q2, s2, z2 = make_linear(N, K, 12)
+    got = e4_image(lin, lin2).cpu().numpy()
+    want = e4_expected(q, s, z, q2, s2, z2)
+    assert got.shape == want.shape and np.array_equal(got, want)
+
+
+# ------------------------------------------------------------------------------------------------ the step
+def int4_model(name, tile_cols=128, mode="gptq.int4-g128", **overrides):
+    cfg = Config.from_name(name, **overrides)
+    sd = {k: v.to(BF) for k, v in synthetic_state_dict(cfg, 4321, perturb=True).items()}
+    qsd = o4.quantize_state_dict(sd, tile_cols, is_linear_key)
+    with L.quantization(mode):
+        model = L.GPT(cfg)
+    model.load_state_dict(qsd, strict=True)
+    return cfg, qsd, model.to(BF).to(DEV).eval()
+
+
+def run_session(model, prompt, n_new, engine, S=None, use_graph=True, follow=None):
+    """Greedy decode through a DecodeSession; returns (tokens, logits of every decode step).  ``follow``: a token
+    sequence that is forced after every step, so that two executors are compared on the same inputs at every position."""
+    T = prompt.numel()
+    total = T + n_new + 1
+    model.reset_cache()
+    model.__dict__.pop("_decode_sessions", None)
+    sess = gb.DecodeSession(model, S or total, total, True, use_graph=use_graph, engine=engine)
+    assert (sess.eng is not None) == engine
+    with torch.no_grad():
+        logits = sess.prefill(prompt.to(DEV))
+        L.ops.argmax_advance(logits, sess.tokens, sess.pos)
+        if follow is not None:
+            sess.tokens[: T + 1].copy_(follow[: T + 1])
+        sess.capture()
+        steps = []
+        for i in range(n_new - 1):
+            steps.append(sess.step().float().cpu().clone())
+            if follow is not None:
+                sess.tokens[: T + i + 2].copy_(follow[: T + i + 2])
+    if sess.eng is not None:
+        sess.eng.check_error()
+    assert int(sess.pos.item()) == T + n_new - 1
+    return sess.tokens[: T + n_new].cpu().clone(), torch.stack(steps)
+
+
+def assert_same_step(log_a, log_b, tok_a, tok_b, T):
+    """Two executors fed the same tokens: logits equal up to the different fp32 summation order of the GEMVs, and the
+    engine's arg-max is an arg-max of the other's logits up to that noise."""
+    d = (log_a - log_b).abs()
+    scale = max(1.0, float(log_a.abs().max()))
+    assert float(d.max()) <= 2 ** -5 * scale, float(d.max())
+    assert float(d.mean()) <= 2e-3 * scale, float(d.mean())
+    for i in range(log_a.shape[0]):
+        t = int(tok_b[T + 1 + i])
+        assert float(log_a[i].max() - log_a[i][t]) <= 2 ** -5 * scale, (i, t)
+
+
+@pytest.mark.parametrize("name", ["tiny-llama", "tiny-llama-hs128", "tiny-llama-gqa"])
+def test_engine_step_equals_the_multi_launch_step(name):
+    cfg, qsd, model = int4_model(name)
+    assert StreamEngine.supported(model) is None
+    prompt = synthetic_prompt(cfg, 9, 3)
+    tok_a, log_a = run_session(model, prompt, 24, engine=False)
+    tok_b, log_b = run_session(model, prompt, 24, engine=True, follow=tok_a.to(DEV))
+    assert_same_step(log_a, log_b, tok_a, tok_b, 9)
+    # free-running engine: graph replay, eager launches and a second run give identical tokens and logits
+    tok_c, log_c = run_session(model, prompt, 24, engine=True)
+    tok_d, log_d = run_session(model, prompt, 24, engine=True, use_graph=False)
+    assert torch.equal(tok_c, tok_d) and torch.equal(log_c, log_d)
+    tok_e, log_e = run_session(model, prompt, 24, engine=True)
+    assert torch.equal(tok_c, tok_e) and torch.equal(log_c, log_e)
+    # against the oracle: logits within the int4 bound
+    oracle = om.OracleGPT(cfg, qsd, "gptq", tile_cols=128)
+    with torch.no_grad():
+        pos = torch.arange(9)
+        oracle(tok_c[:9].view(1, -1), 40, pos)
+        for i in range(9, 14):
+            ref = oracle(tok_c[i].view(1, 1), 40, torch.tensor([i]))[0, -1].float()
+            d = (log_c[i - 9] - ref).abs()
+            assert float(d.max()) <= 1.5e-2 * max(1.0, float(ref.abs().max())) and float(d.mean()) <= 3e-3
+
+
+def test_engine_ring_window_and_generate(monkeypatch):
+    """generate() end to end on the engine, with a window smaller than the sequence (ring slots) and sampling."""
+    cfg, qsd, model = int4_model("tiny-llama")
+    prompt = synthetic_prompt(cfg, 6, 5)
+    monkeypatch.setattr(gb, "ENGINE_DEFAULT", True)
+    y = L.generate(model, prompt.to(DEV), 40, 40, top_k=1).cpu()
+    sess = next(iter(model._decode_sessions.values()))
+    assert sess.eng is not None and sess.graph is not None
+    sess.eng.check_error()
+    oracle = om.OracleGPT(cfg, qsd, "gptq", tile_cols=128)
+    y_ref = om.generate(oracle, prompt, 40, 40, greedy_ties_lowest=True)
+    assert float((y == y_ref).float().mean()) >= 0.9
+    # a window of 16 slots under 40 positions: the ring wraps twice; same tokens as the multi-launch step on the same window
+    tok_a, log_a = run_session(model, prompt, 30, engine=False, S=16)
+    tok_b, log_b = run_session(model, prompt, 30, engine=True, S=16, follow=tok_a.to(DEV))
+    assert_same_step(log_a, log_b, tok_a, tok_b, 6)
+    # non-greedy: the launch stops at the logits, the reference's sampling ops draw the token
+    model.reset_cache()
+    torch.manual_seed(3)
+    a = L.generate(model, prompt.to(DEV), 20, 20, temperature=0.9, top_k=4).cpu()
+    model.reset_cache()
+    torch.manual_seed(3)
+    b = L.generate(model, prompt.to(DEV), 20, 20, temperature=0.9, top_k=4).cpu()
+    assert torch.equal(a, b)
+    next(iter(model._decode_sessions.values())).eng.check_error()
+
+
+def test_engine_refuses_unsupported_models():
+    model = L.GPT(Config.from_name("tiny-neox")).to(BF).to(DEV)  # head size 32, dense bf16 Linears
+    assert StreamEngine.supported(model) is not None
+    cfg, _, m2 = int4_model("tiny-llama", tile_cols=32, mode="gptq.int4-g32")
+    assert "group size" in StreamEngine.supported(m2)
+    with pytest.raises(_hip.ParrotHipError):
+        StreamEngine(m2, torch.zeros(8, dtype=torch.int64, device=DEV), torch.zeros(1, dtype=torch.int32, device=DEV), [], 8, True)

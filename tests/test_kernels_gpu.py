@@ -649,30 +649,6 @@ def test_fused_decode_attention_equals_the_three_kernel_path(n_groups, q_per_kv,
         assert int(tickets.abs().sum()) == 0, "arrival tickets must be re-armed"
 
 
-@pytest.mark.parametrize("n_groups,q_per_kv,hs,n_elem", [(32, 1, 128, 128), (8, 16, 64, 64), (1, 4, 64, 16)])
-def test_fused_decode_attention_with_prefetch_workgroups_is_unchanged(n_groups, q_per_kv, hs, n_elem):
-    """parrot_attn_fused_decode_pf: the extra workgroups only read (ragged, odd-sized and empty ranges); cache and heads
-    are bit-identical to the launch without them, also when the sequence is split."""
-    g = gen(23)
-    n_head, width, S = n_groups * q_per_kv, n_groups * (q_per_kv + 2) * hs, 300
-    cos, sin = (t.to(DEV) for t in om.rope_tables(512, n_elem, BF, math_dtype=BF))
-    ranges = [torch.randint(0, 255, (n,), dtype=torch.uint8, device=DEV) for n in (1 << 20, 48 * 1000 + 16, 16, 0)]
-    for nsplit in (1, 2):
-        kc1 = torch.randn((n_groups, S, hs), generator=g).to(BF).to(DEV); vc1 = torch.randn((n_groups, S, hs), generator=g).to(BF).to(DEV)
-        kc2, vc2 = kc1.clone(), vc1.clone()
-        y1 = torch.empty((1, n_head * hs), dtype=BF, device=DEV); y2 = torch.empty_like(y1)
-        ws1, ws2 = ops.attn_workspace(1, n_head, hs, nsplit, DEV), ops.attn_workspace(1, n_head, hs, nsplit, DEV)
-        t1 = torch.zeros((n_head,), dtype=torch.int32, device=DEV); t2 = torch.zeros_like(t1)
-        for pos in (0, 5, 250, 299, 301):
-            qkv = torch.randn(1, width, generator=g).to(BF).to(DEV)
-            pos_d = torch.tensor([pos], dtype=torch.int32, device=DEV)
-            ops.attn_fused_decode(qkv, cos, sin, n_elem, pos_d, kc1, vc1, n_groups, q_per_kv, hs, S, nsplit, ws1, t1, y1)
-            ops.attn_fused_decode(qkv, cos, sin, n_elem, pos_d, kc2, vc2, n_groups, q_per_kv, hs, S, nsplit, ws2, t2, y2,
-                                  prefetch=ranges, prefetch_wgs=37)
-            assert torch.equal(kc1, kc2) and torch.equal(vc1, vc2) and torch.equal(y1, y2), (nsplit, pos)
-            assert int(t2.abs().sum()) == 0
-
-
 @pytest.mark.parametrize("n_groups,q_per_kv,hs", [(4, 1, 128), (2, 4, 64), (1, 3, 32), (8, 16, 64)])
 @pytest.mark.parametrize("M,S,pos0", [(32, 32, 0), (100, 128, 0), (257, 300, 0), (70, 200, 37), (512, 512, 0)])
 def test_prefill_attention_on_the_matrix_cores_equals_the_row_by_row_path(n_groups, q_per_kv, hs, M, S, pos0):
