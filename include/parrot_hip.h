@@ -278,7 +278,8 @@ typedef struct parrot_eng_state {
     int32_t greedy;             /* 1: tokens[pos + 1] = argmax(logits), pos += 1 inside the launch */
     int32_t lds_buf0_bytes, lds_buf1_bytes; /* from parrot_eng_lds_bytes */
     uint64_t* arg;              /* 2 * 256 granules: every CU's arg-max candidate {value, index} */
-    uint64_t* dbg;              /* NULL, or nops * 4 words: 100 MHz stamps of workgroup 0 (diagnostic runs only) */
+    uint64_t* dbg;              /* NULL, or nops * 8 words: 100 MHz stamps of workgroup 0 (diagnostic runs only) */
+    uint64_t* dbg_all;          /* NULL, or nops * 256 * 2 words: {input ready, units done} stamps of every workgroup */
 } parrot_eng_state_t;
 
 /* bytes of the E4 image of an (N, K) int4 matrix with group 128 (dual = 1: the SwiGLU pair, N rows each) */

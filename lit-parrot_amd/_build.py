@@ -34,6 +34,8 @@ def _compile_one(args):
     cmd = [exe, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", "-Wall", "-Wno-unused-function", "-c", src, "-o", obj]
     if diag:  # diagnostic build: environment A/B switches and the stamp / tuning hooks of tools/ (never the shipped library)
         cmd.insert(1, "-DPARROT_DIAG")
+    for d in os.environ.get("PARROT_BUILD_DEFINES", "").split():  # experiment builds of tools/ab_*.sh: e.g. ENG_THIN_PIECES=8
+        cmd.insert(1, "-D" + d)
     if verbose:
         print(" ".join(cmd))
     proc = subprocess.run(cmd, capture_output=True, text=True)

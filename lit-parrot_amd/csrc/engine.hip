@@ -5,13 +5,13 @@
 // (:194-275) -> out-projection + residual -> RMSNorm -> SwiGLU MLP (:290-301) + residual, then ln_f, lm_head, arg-max.
 //
 // Why one launch: the multi-launch step pays a ramp, a tail and a kernel boundary (~4 us in all) 161 times per token with
-// the HBM idle in between.  Here 256 workgroups (one per CU, 8 waves) stay resident for the whole token:
+// the HBM idle in between.  Here 256 workgroups (one per CU, 16 waves) stay resident for the whole token:
 //   * wave 0 is the LOADER.  It walks the CU's share of the token's byte stream - for every Linear the CU's blocks of
 //     8 output rows in the E4 layout, for every attention op the K/V rows of the CU's key range - and moves it into a
 //     ring of 7 LDS slots (17 KiB each) by LDS-DMA (global_load_lds_dwordx4, 1 KiB per wave instruction).  It never
 //     waits for a data dependency, only for a free slot, so the weights of the ops behind an activation hand-off are
 //     already on chip when the hand-off completes;
-//   * waves 1..7 are CONSUMERS.  Per op they gather the input vector into LDS (normalised, bf16), then take the op's
+//   * waves 1..15 are CONSUMERS.  Per op they gather the input vector into LDS (normalised, bf16), then take the op's
 //     work units round-robin as their slots land: a QUAD = 8 rows x 1024 columns (four 1-KiB pieces + one metadata
 //     word per lane) for a Linear, a K piece + V piece for attention.  Lane l of a piece holds the 32-column slice of
 //     row l % 8 in quantisation group 8 * quad + l / 8, so a lane accumulates whole groups and the only cross-lane
@@ -28,17 +28,31 @@
 
 namespace parrot {
 
+// experiment builds (tools/ab_engine.sh) override these
+#ifndef ENG_THIN_PIECES_V
+#define ENG_THIN_PIECES_V 4
+#endif
+#ifndef ENG_MAXFLY_V
+#define ENG_MAXFLY_V 3
+#endif
+#ifndef ENG_ATTN_GATE
+#define ENG_ATTN_GATE 0
+#endif
+#ifndef ENG_NORM_AHEAD
+#define ENG_NORM_AHEAD 0
+#endif
 constexpr int ENG_WGS = PARROT_ENG_WGS;
-constexpr int ENG_NC = 7;                 // consumer waves
+constexpr int ENG_NC = 15;                // consumer waves
 constexpr int ENG_THREADS = (ENG_NC + 1) * 64;
 constexpr int ENG_NSLOT = 7;              // ring slots
 constexpr int ENG_SLOT_BYTES = 17 * 1024;
 constexpr int ENG_META_OFF = 16 * 1024;   // the metadata piece of a slot, in LDS
-constexpr int ENG_MAXG = 13;              // input groups (128 elements) per consumer wave: K <= 7 * 13 * 128 = 11648
+constexpr int ENG_MAXG = 6;               // input groups (128 elements) per consumer wave: K <= 15 * 6 * 128 = 11520
 constexpr int ENG_MAXQ = 11;              // quads per block: K <= 11264
 constexpr int ENG_RED = 16;               // block result buffers in flight
 constexpr int ENG_GROUP_STRIDE = 272;     // LDS bytes per 128-element group of an activation buffer (256 + 16: bank spread)
-constexpr int ENG_MAXFLY = 3;             // ring slots with LDS-DMA in flight (vmcnt counts at most 63 operations)
+constexpr int ENG_MAXFLY = ENG_MAXFLY_V;             // ring slots with LDS-DMA in flight (vmcnt counts at most 63 operations)
+constexpr int ENG_THIN_PIECES = ENG_THIN_PIECES_V;  // prefetch slots (ops behind a hand-off) are issued with at most this many pieces outstanding
 constexpr unsigned ENG_SPINS_LDS = 2000000u;
 constexpr unsigned ENG_SPINS_GLOBAL = 60000u;
 
@@ -50,17 +64,20 @@ constexpr int EF_XS = 0;                                  // [2][128] float: per
 constexpr int EF_RED = EF_XS + 2 * 128 * 4;               // [ENG_RED][ENG_MAXQ][8] float
 constexpr int EF_ROPE = EF_RED + ENG_RED * ENG_MAXQ * 8 * 4;  // [2][128] float: cos / sin row of this position
 constexpr int EF_RESID = EF_ROPE + 2 * 128 * 4;           // [64] float: the CU's own rows of the residual stream
-constexpr int EF_STAT = EF_RESID + 64 * 4;                // [8] float
-constexpr int EF_BESTV = EF_STAT + 32;                    // [8] float
-constexpr int EF_BESTI = EF_BESTV + 32;                   // [8] int
-constexpr int EF_FULL = EF_BESTI + 32;                    // [8] u32: sequence number + 1 of the slot's landed contents
+constexpr int EF_STAT = EF_RESID + 64 * 4;                // [16] float
+constexpr int EF_BESTV = EF_STAT + 64;                    // [16] float
+constexpr int EF_BESTI = EF_BESTV + 64;                   // [16] int
+constexpr int EF_FULL = EF_BESTI + 64;                    // [8] u32: sequence number + 1 of the slot's landed contents
 constexpr int EF_CONS = EF_FULL + 32;                     // [8] u32: units consumed from the ring slot, cumulative
 constexpr int EF_EXP = EF_CONS + 32;                      // [8] u32 (loader): units issued into the ring slot, cumulative
 constexpr int EF_NPQ = EF_EXP + 32;                       // [8] u32 (loader): pieces of the issued, unpublished slots
 constexpr int EF_DONE = EF_NPQ + 32;                      // [ENG_RED] u32: quads finished of a block
 constexpr int EF_CB = EF_DONE + ENG_RED * 4;              // consumer barrier counter
 constexpr int EF_ABORT = EF_CB + 4;
-constexpr int EF_BYTES = EF_ABORT + 12;
+constexpr int EF_GATE = EF_ABORT + 4;                     // op index + 1 whose input producers were seen to be done (one poller per CU)
+constexpr int EF_GATE2 = EF_GATE + 4;                     // the same for the attention leader's wait for the partial states
+constexpr int EF_CUR = EF_GATE2 + 4;                      // index of the op whose input the consumers have (loader: how urgent a slot is)
+constexpr int EF_BYTES = EF_CUR + 8;
 
 typedef __attribute__((address_space(3))) uint32_t lds_u32_t;
 typedef const __attribute__((address_space(4))) uint32_t* cst_cu32_t;
@@ -198,6 +215,20 @@ __device__ __forceinline__ void eng_wait_lds_ge(const EngState& st, const EngCtx
     }
 }
 
+// the same without sleeping between polls: for waits that are a few hundred cycles long (the consumer barrier)
+__device__ __forceinline__ void eng_wait_lds_ge_tight(const EngState& st, const EngCtx& c, int off, uint32_t target, uint32_t code) {
+    unsigned spins = 0;
+    while ((int32_t)(lds_ld(c.fx + off) - target) < 0) {
+        if ((++spins & 255u) == 0) {
+            if (eng_aborted(c)) return;
+            if (spins > 4 * ENG_SPINS_LDS) {
+                eng_fail(st, c, code);
+                return;
+            }
+        }
+    }
+}
+
 // blocks of op that CU c owns: [b0, b1)
 __device__ __forceinline__ void eng_block_range(int nblocks, int cu, int& b0, int& b1) {
     b0 = (int)(((int64_t)cu * nblocks) / ENG_WGS);
@@ -230,6 +261,7 @@ __device__ __forceinline__ void eng_loader(const EngState& st, const EngCtx& c) 
     constexpr int KPP = 512 / HS;
     const unsigned ring_lds = (unsigned)(uintptr_t)c.ring;
     int seq = 0, pub = 0, inflight = 0;
+    __builtin_amdgcn_s_setprio(3);  // a handful of instructions per slot: never behind the consumers' arithmetic
 
     auto publish_oldest = [&]() {
         const int np = (int)lds_ld(c.fx + EF_NPQ + (pub & 7) * 4);
@@ -238,8 +270,12 @@ __device__ __forceinline__ void eng_loader(const EngState& st, const EngCtx& c) 
         lds_st(c.fx + EF_FULL + (pub % ENG_NSLOT) * 4, (uint32_t)(pub + 1));
         ++pub;
     };
-    // wait for ring slot seq % NSLOT to be free; returns the cumulative unit count it had
-    auto acquire = [&](int np) -> uint32_t {
+    // wait for ring slot seq % NSLOT to be free; returns the cumulative unit count it had.
+    // A hand-off's stores and polls queue behind whatever this CU has in flight (measured: one granule load took 0.5 us
+    // with the loader idle, 1.6 - 3 us behind three slots of LDS-DMA).  Slots of the op the consumers are computing are
+    // urgent and go out three deep; slots of ops whose input is still outstanding are prefetch: one slot in flight, so that
+    // the epilogue stores of the current op and the polls of the next one pass quickly.
+    auto acquire = [&](int np, int k) -> uint32_t {
         const int r = seq % ENG_NSLOT;
         const uint32_t target = lds_ld(c.fx + EF_EXP + r * 4);
         if (lds_ld(c.fx + EF_CONS + r * 4) != target) {
@@ -247,6 +283,8 @@ __device__ __forceinline__ void eng_loader(const EngState& st, const EngCtx& c) 
             eng_wait_lds_ge(st, c, EF_CONS + r * 4, target, 0x10000000u | (uint32_t)seq);
         }
         while (seq - pub >= ENG_MAXFLY || inflight + np > 60) publish_oldest();
+        if (k > (int)lds_ld(c.fx + EF_CUR))
+            while (inflight > ENG_THIN_PIECES && pub < seq) publish_oldest();
         return target;
     };
     auto commit = [&](uint32_t target, int np, int nunits) {
@@ -260,6 +298,10 @@ __device__ __forceinline__ void eng_loader(const EngState& st, const EngCtx& c) 
     for (int k = 0; k < st.nops; ++k) {
         const EngOp opv = eng_fetch_op(st.ops, k);
         const EngOp* op = &opv;
+        if (st.dbg != nullptr && c.cu == 0 && c.lane == 0) {  // diagnostic: when the loader reaches the op, and what it has announced by then
+            st.dbg[k * 8 + 4] = __builtin_amdgcn_s_memrealtime();
+            st.dbg[k * 8 + 5] = (uint64_t)seq | ((uint64_t)pub << 32);
+        }
         if (op->type == PARROT_ENG_GEMV) {
             int b0, b1;
             eng_block_range(op->nblocks, c.cu, b0, b1);
@@ -269,7 +311,7 @@ __device__ __forceinline__ void eng_loader(const EngState& st, const EngCtx& c) 
                 for (int sib = 0; sib < spb; ++sib) {
                     const int nqs = min(4, nq - 4 * sib);
                     const int np = 4 * nqs + 1;
-                    const uint32_t target = acquire(np);
+                    const uint32_t target = acquire(np, k);
                     const unsigned char* src = reinterpret_cast<const unsigned char*>(op->W) + (int64_t)b * block_bytes +
                                                (int64_t)sib * ENG_SLOT_BYTES + c.lane * 16;
                     const unsigned dst = __builtin_amdgcn_readfirstlane(ring_lds + (unsigned)((seq % ENG_NSLOT) * ENG_SLOT_BYTES));
@@ -285,7 +327,7 @@ __device__ __forceinline__ void eng_loader(const EngState& st, const EngCtx& c) 
             const unsigned char* vg = reinterpret_cast<const unsigned char*>(op->v_cache) + (int64_t)ky.g * grp_bytes;
             for (int u0 = 0; u0 < ky.nunits; u0 += 8) {
                 const int nu = min(8, ky.nunits - u0);
-                const uint32_t target = acquire(2 * nu);
+                const uint32_t target = acquire(2 * nu, k);
                 const unsigned dst = __builtin_amdgcn_readfirstlane(ring_lds + (unsigned)((seq % ENG_NSLOT) * ENG_SLOT_BYTES));
                 for (int uu = 0; uu < nu; ++uu) {
                     // rows past the group's last one are clamped to it (loaded, never used)
@@ -308,6 +350,9 @@ struct EngCons {
     int bc;           // running block count of this CU (result buffer index)
     float best;       // lm_head: this wave's best logit so far (its epilogue lanes)
     int best_i;
+    uint64_t waited;  // diagnostic: 100 MHz ticks this wave spent waiting for ring slots in the current op
+    unsigned gate_spins;  // diagnostic: polls of the gather's first granule
+    uint32_t nwv[ENG_MAXG];  // this wave's share of the NEXT norm's weights (constants: fetched an op ahead, off the hand-off)
 };
 
 // barrier over the consumer waves (the loader never joins)
@@ -315,9 +360,15 @@ __device__ __forceinline__ void eng_cbar(const EngState& st, const EngCtx& c, En
     lds_drain();
     w.cb_gen += ENG_NC;
     if (c.lane == 0) lds_add(c.fx + EF_CB, 1u);
-    eng_wait_lds_ge(st, c, EF_CB, w.cb_gen, 0x20000000u | w.cb_gen);
+    eng_wait_lds_ge_tight(st, c, EF_CB, w.cb_gen, 0x20000000u | w.cb_gen);
 }
-__device__ __forceinline__ void eng_wait_full(const EngState& st, const EngCtx& c, int seq) {
+__device__ __forceinline__ void eng_wait_full(const EngState& st, const EngCtx& c, EngCons& w, int seq) {
+    if (st.dbg != nullptr) {
+        const uint64_t t0 = __builtin_amdgcn_s_memrealtime();
+        eng_wait_lds_ge(st, c, EF_FULL + (seq % ENG_NSLOT) * 4, (uint32_t)(seq + 1), 0x30000000u | (uint32_t)seq);
+        w.waited += __builtin_amdgcn_s_memrealtime() - t0;
+        return;
+    }
     eng_wait_lds_ge(st, c, EF_FULL + (seq % ENG_NSLOT) * 4, (uint32_t)(seq + 1), 0x30000000u | (uint32_t)seq);
 }
 __device__ __forceinline__ void eng_release(const EngCtx& c, int seq) {
@@ -325,13 +376,16 @@ __device__ __forceinline__ void eng_release(const EngCtx& c, int seq) {
     if (c.lane == 0) lds_add(c.fx + EF_CONS + (seq % ENG_NSLOT) * 4, 1u);
 }
 __device__ __forceinline__ void eng_stamp(const EngState& st, const EngCtx& c, const EngCons& w, int k, int i) {
-    if (st.dbg != nullptr && c.cu == 0 && w.cw == 0 && c.lane == 0) st.dbg[k * 4 + i] = __builtin_amdgcn_s_memrealtime();
+    if (st.dbg != nullptr && c.cu == 0 && w.cw == 0 && c.lane == 0) st.dbg[k * 8 + i] = __builtin_amdgcn_s_memrealtime();
+    // every CU's {input ready, own units done} times of every op (the 100 MHz clock is chip-wide): who is late
+    if (st.dbg_all != nullptr && (i == 1 || i == 2) && w.cw == 0 && c.lane == 0)
+        st.dbg_all[((int64_t)k * ENG_WGS + c.cu) * 2 + (i - 1)] = __builtin_amdgcn_s_memrealtime();
 }
 
 // Wait until the 64 granules at p (one per lane; lanes with !need are not checked) carry this launch's tag; returns the
 // data words.  v holds the first attempt.
 __device__ __forceinline__ uint32_t eng_gran_wait(const EngState& st, const EngCtx& c, const uint64_t* p, uint64_t v, bool need,
-                                                 uint32_t code) {
+                                                 uint32_t code, unsigned* nspins = nullptr) {
     unsigned spins = 0;
     while (!__all(!need || (uint32_t)(v >> 32) == c.epoch)) {
         __builtin_amdgcn_s_sleep(2);
@@ -344,11 +398,29 @@ __device__ __forceinline__ uint32_t eng_gran_wait(const EngState& st, const EngC
         }
         v = ld_gran(p);
     }
+    if (nspins != nullptr) *nspins = spins;
     return (uint32_t)v;
 }
 
+// this wave's share of the weights of the norm in front of op k (if it has one) -> registers, requested an op ahead: the
+// loads are in order with the hand-off polls (vmcnt), so a 2 - 3 us HBM miss here would otherwise sit in front of them
+__device__ __forceinline__ void eng_prefetch_norm(const EngState& st, const EngCtx& c, EngCons& w, int k) {
+    if (k >= st.nops) return;
+    const EngOp op = eng_fetch_op(st.ops, k);
+    if (op.type != PARROT_ENG_GEMV || op.norm_kind != 1) return;
+    glb_cu32_t nw = (glb_cu32_t)op.norm_w;
+    const int npairs = op.K >> 1, ngr = (op.K + 127) >> 7;
+#pragma unroll
+    for (int i = 0; i < ENG_MAXG; ++i) {
+        const int g = w.cw + ENG_NC * i;
+        if (g < ngr) w.nwv[i] = nw[min(64 * g + c.lane, npairs - 1)];
+    }
+}
+
 // ---- input vector of a GEMV op -> LDS activation buffer (normalised bf16, per-group sums)
-__device__ __forceinline__ void eng_gather(const EngState& st, const EngCtx& c, EngCons& w, const EngOp* op, int k) {
+__device__ __forceinline__ void eng_gather(const EngState& st, const EngCtx& c0, EngCons& w, const EngOp* op, int k) {
+    EngCtx c = c0;
+    asm volatile("" : "+v"(c.lane));  // an opaque copy per op: addresses derived from the lane are not hoisted out of the op loop
     const int K = op->K;
     const int npairs = K >> 1;
     const int ngr = (K + 127) >> 7;
@@ -356,13 +428,12 @@ __device__ __forceinline__ void eng_gather(const EngState& st, const EngCtx& c, 
     unsigned char* buf = op->buf ? c.buf1 : c.buf0;
     float* xs = reinterpret_cast<float*>(c.fx + EF_XS) + op->buf * 128;
     uint32_t xv[ENG_MAXG], nwv[ENG_MAXG];
-    // the norm weights are constants: requested before the wait for the producers, not behind it
-    glb_cu32_t nw = (glb_cu32_t)op->norm_w;
 #pragma unroll
-    for (int i = 0; i < ENG_MAXG; ++i) {
-        const int g = w.cw + ENG_NC * i;
-        nwv[i] = 0;
-        if (op->norm_kind == 1 && g < ngr) nwv[i] = nw[min(64 * g + c.lane, npairs - 1)];
+    for (int i = 0; i < ENG_MAXG; ++i) nwv[i] = w.nwv[i];  // fetched while the previous op ran (eng_prefetch_norm)
+    if (!ENG_NORM_AHEAD) {
+        eng_prefetch_norm(st, c, w, k);
+#pragma unroll
+        for (int i = 0; i < ENG_MAXG; ++i) nwv[i] = w.nwv[i];
     }
     if (op->in_embedding) {
         glb_cu32_t e32 = (glb_cu32_t)c.emb;
@@ -378,11 +449,18 @@ __device__ __forceinline__ void eng_gather(const EngState& st, const EngCtx& c, 
         }
     } else {
         const uint64_t* in = op->in;
-        // poll one granule until the producers are about done, then sweep the whole share until every tag matches
-        {
-            const int pr = 64 * w.cw + c.lane;
-            if (w.cw < ngr) (void)eng_gran_wait(st, c, in + min(pr, npairs - 1), 0, pr < npairs, 0x40000000u | (uint32_t)k);
+        // ONE wave polls ONE granule (the vector's last: a single 8-byte request per poll and CU - 3840 waves polling 512 B
+        // each cost every hand-off its latency) until the producers are about done; the others wait on an LDS word; then
+        // every wave sweeps its share until every tag matches
+        if (w.cw == 0) {
+            unsigned gs = 0;
+            (void)eng_gran_wait(st, c, in + (npairs - 1), 0, true, 0x40000000u | (uint32_t)k, &gs);
+            w.gate_spins = gs;
+            if (c.lane == 0) lds_st(c.fx + EF_GATE, (uint32_t)(k + 1));
+        } else {
+            eng_wait_lds_ge(st, c, EF_GATE, (uint32_t)(k + 1), 0x42000000u | (uint32_t)k);
         }
+        eng_stamp(st, c, w, k, 6);
         unsigned spins = 0;
         for (;;) {
             uint64_t gv[ENG_MAXG];
@@ -410,6 +488,7 @@ __device__ __forceinline__ void eng_gather(const EngState& st, const EngCtx& c, 
             }
         }
     }
+    eng_stamp(st, c, w, k, 7);
     float r = 1.f;
     NormArgs na;
     na.kind = op->norm_kind;
@@ -446,10 +525,14 @@ __device__ __forceinline__ void eng_gather(const EngState& st, const EngCtx& c, 
 }
 
 // ---- one Linear: the CU's blocks, quads dealt round-robin over the consumer waves
-__device__ __forceinline__ void eng_gemv(const EngState& st, const EngCtx& c, EngCons& w, const EngOp* op, int k) {
-    eng_stamp(st, c, w, k, 0);
-    eng_gather(st, c, w, op, k);
+__device__ __forceinline__ void eng_gemv(const EngState& st, const EngCtx& c0, EngCons& w, const EngOp* op, int k) {
+    eng_stamp(st, c0, w, k, 0);
+    eng_gather(st, c0, w, op, k);
+    EngCtx c = c0;
+    asm volatile("" : "+v"(c.lane));
+    if (w.cw == 0 && c.lane == 0) lds_st(c.fx + EF_CUR, (uint32_t)k);
     eng_stamp(st, c, w, k, 1);
+    if (ENG_NORM_AHEAD) eng_prefetch_norm(st, c, w, k + 1);
     int b0, b1;
     eng_block_range(op->nblocks, c.cu, b0, b1);
     const int nq = op->nq, spb = (nq + 3) >> 2;
@@ -460,38 +543,49 @@ __device__ __forceinline__ void eng_gemv(const EngState& st, const EngCtx& c, En
     const int r = c.lane & 7, p = c.lane >> 3;
     const int epi = op->epilogue;
     const int total = (b1 - b0) * nq;
+    // quads are dealt round-robin over the consumer waves: wave cw takes quads cw, cw + NC, ...; (bl, Q) = (local block,
+    // quad of the row) are stepped without a division per quad
+    int bl = w.cw / nq, Q = w.cw - bl * nq;
+    const int step_b = ENG_NC / nq, step_q = ENG_NC - step_b * nq;
     for (int idx = w.cw; idx < total; idx += ENG_NC) {
-        const int bl = idx / nq, Q = idx - bl * nq;  // local block, quad of the row
         const int b = b0 + bl;
         const int sib = Q >> 2, qq = Q & 3;
         const int seq = w.seq + bl * spb + sib;
-        eng_wait_full(st, c, seq);
+        eng_wait_full(st, c, w, seq);
         const unsigned char* slot = c.ring + (seq % ENG_NSLOT) * ENG_SLOT_BYTES;
         const uint32_t mt = *reinterpret_cast<const uint32_t*>(slot + ENG_META_OFF + (qq * 64 + c.lane) * 4);
         const int G = 8 * Q + p;
         const unsigned char* xg = buf + G * ENG_GROUP_STRIDE;
-        float acc = 0.f;
+        const unsigned char* wq = slot + qq * 4096 + c.lane * 16;
+        // one accumulator pair over the quad's four pieces (= the lane's whole quantisation group)
+        float p0 = 0.f, p1 = 0.f;
+        const uint32_t mask = 0x000F000Fu;
+        uint32_t magic = 0x43004300u;
+        asm("" : "+v"(magic));
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const uint4 wv = *reinterpret_cast<const uint4*>(slot + (qq * 4 + i) * 1024 + c.lane * 16);
-            uint32_t xr[16];
+            const uint4 wv = *reinterpret_cast<const uint4*>(wq + i * 1024);
+            const uint32_t dw[4] = {wv.x, wv.y, wv.z, wv.w};
 #pragma unroll
-            for (int q4 = 0; q4 < 4; ++q4) {
-                const uint4 xv = *reinterpret_cast<const uint4*>(xg + i * 64 + q4 * 16);
-                xr[4 * q4 + 0] = xv.x;
-                xr[4 * q4 + 1] = xv.y;
-                xr[4 * q4 + 2] = xv.z;
-                xr[4 * q4 + 3] = xv.w;
+            for (int d = 0; d < 4; ++d) {
+                const uint4 xv = *reinterpret_cast<const uint4*>(xg + i * 64 + d * 16);
+                p0 = dot2_bf16(and_or(dw[d], mask, magic), xv.x, p0);
+                p1 = dot2_bf16(and_or(dw[d] >> 4, mask, magic), xv.y, p1);
+                p0 = dot2_bf16(and_or(dw[d] >> 8, mask, magic), xv.z, p0);
+                p1 = dot2_bf16(and_or(dw[d] >> 12, mask, magic), xv.w, p1);
             }
-            acc += w4_slice_dot(wv, xr);
         }
+        const float acc = p0 + p1;
         float v = bflo(mt) * (acc - (128.0f + bfhi(mt)) * xs[G]);
         v = row8_allsum(v);
         const int rb = (w.bc + bl) % ENG_RED;
         if (c.lane < 8) red[(rb * ENG_MAXQ + Q) * 8 + c.lane] = v;
-        eng_release(c, seq);  // (drains LDS: the partial sums above are written)
+        lds_drain();  // this wave's reads of the slot have returned, its partial sums are written
         uint32_t t = 0;
-        if (c.lane == 0) t = lds_add(c.fx + EF_DONE + rb * 4, 1u);
+        if (c.lane == 0) {
+            lds_add(c.fx + EF_CONS + (seq % ENG_NSLOT) * 4, 1u);
+            t = lds_add(c.fx + EF_DONE + rb * 4, 1u);
+        }
         t = __builtin_amdgcn_readfirstlane(t);
         if ((int)t == nq - 1) {
             // ---- this wave finished the block's last quad: fixed-order sum, epilogue, publish
@@ -528,17 +622,27 @@ __device__ __forceinline__ void eng_gemv(const EngState& st, const EngCtx& c, En
                     st_gran(reinterpret_cast<uint64_t*>(op->out) + ((b * rows + c.lane) >> 1), ob | (nb << 16), c.epoch);
             }
         }
+        bl += step_b;
+        Q += step_q;
+        if (Q >= nq) {
+            Q -= nq;
+            ++bl;
+        }
     }
     w.seq += (b1 - b0) * spb;
     w.bc += b1 - b0;
     eng_stamp(st, c, w, k, 2);
+    if (st.dbg != nullptr && c.cu == 0 && w.cw == 0 && c.lane == 0) st.dbg[k * 8 + 3] = w.waited | ((uint64_t)w.gate_spins << 40);
+    w.waited = 0;
 }
 
 // ---- attention op: split + RoPE + KV append + softmax(q k^T / sqrt(hs)) v over the CU's key range, partial states to the
 // group's leader CU, which merges them into the heads
 template <int HS, int HQ>
-__device__ __forceinline__ void eng_attn(const EngState& st, const EngCtx& c, EngCons& w, const EngOp* op, int k) {
+__device__ __forceinline__ void eng_attn(const EngState& st, const EngCtx& c0, EngCons& w, const EngOp* op, int k) {
     constexpr int LPR = HS / 8, KPP = 64 / LPR, PW = HS + 2;
+    EngCtx c = c0;
+    asm volatile("" : "+v"(c.lane));
     eng_stamp(st, c, w, k, 0);
     const EngKeys ky = eng_keys<HS>(st, c.cu, c.pos);
     if (!ky.part) {
@@ -549,7 +653,7 @@ __device__ __forceinline__ void eng_attn(const EngState& st, const EngCtx& c, En
     unsigned char* sc = c.buf0;
     uint32_t* raw = reinterpret_cast<uint32_t*>(sc);                                      // [(HQ + 2) * HS / 2] bf16 pairs
     float* wpart = reinterpret_cast<float*>(sc + (HQ + 2) * HS * 2);                      // [NC][HQ][PW]
-    float* stage = wpart + ENG_NC * HQ * PW;                                              // [nsplit * PW]
+    float* stage = wpart + ENG_NC * HQ * PW;                                              // [HQ][nsplit][PW]
     const float* rope = reinterpret_cast<const float*>(c.fx + EF_ROPE);
     const int dl = c.lane % LPR, j = c.lane / LPR;
     const int n_elem = st.n_elem, half_n = n_elem >> 1;
@@ -558,6 +662,13 @@ __device__ __forceinline__ void eng_attn(const EngState& st, const EngCtx& c, En
     {
         constexpr int NPAIR = (HQ + 2) * HS / 2, NLOAD = (NPAIR + 63) / 64;
         const uint64_t* in = op->in + (int64_t)ky.g * NPAIR;
+        if (!ENG_ATTN_GATE) {
+        } else if (w.cw == 0) {  // one poller per CU (see eng_gather)
+            (void)eng_gran_wait(st, c, in + (NPAIR - 1), 0, true, 0x52000000u | (uint32_t)k);
+            if (c.lane == 0) lds_st(c.fx + EF_GATE, (uint32_t)(k + 1));
+        } else if (w.cw < NLOAD) {
+            eng_wait_lds_ge(st, c, EF_GATE, (uint32_t)(k + 1), 0x53000000u | (uint32_t)k);
+        }
         for (int t = w.cw; t < NLOAD; t += ENG_NC) {
             const int pr = 64 * t + c.lane;
             const uint64_t* p = in + min(pr, NPAIR - 1);
@@ -567,25 +678,55 @@ __device__ __forceinline__ void eng_attn(const EngState& st, const EngCtx& c, En
     }
     eng_cbar(st, c, w);
     eng_stamp(st, c, w, k, 1);
-    // this lane's 8 dims of every query head (RoPE, rounded to bf16, scaled), of the new key (RoPE) and the new value
+    if (w.cw == 0 && c.lane == 0) lds_st(c.fx + EF_CUR, (uint32_t)k);
+    // this lane's 8 dims of every query head (RoPE, rounded to bf16, scaled), of the new key (RoPE) and the new value.
+    // The rotary width is a multiple of 16 (checked on the host), so a lane's 8 dims lie on one side of the rotation.
     const bf16_t* rawb = reinterpret_cast<const bf16_t*>(raw);
-    auto roped = [&](int row, int d) -> bf16_t {
-        const float x = bf2f(rawb[row * HS + d]);
-        if (d >= n_elem) return rawb[row * HS + d];
-        const float other = d < half_n ? -bf2f(rawb[row * HS + d + half_n]) : bf2f(rawb[row * HS + d - half_n]);
-        return f2bf(__fadd_rn(__fmul_rn(x, rope[d]), __fmul_rn(other, rope[128 + d])));
+    const int d0 = dl * 8;
+    const bool rot = d0 < n_elem, lo = d0 < half_n;
+    const int dpart = rot ? (lo ? d0 + half_n : d0 - half_n) : d0;
+    float cs[8], sn[8];
+    {
+        const int dr = rot ? d0 : 0;
+        const float4 c0 = *reinterpret_cast<const float4*>(rope + dr), c1 = *reinterpret_cast<const float4*>(rope + dr + 4);
+        const float4 s0 = *reinterpret_cast<const float4*>(rope + 128 + dr), s1 = *reinterpret_cast<const float4*>(rope + 128 + dr + 4);
+        cs[0] = c0.x; cs[1] = c0.y; cs[2] = c0.z; cs[3] = c0.w; cs[4] = c1.x; cs[5] = c1.y; cs[6] = c1.z; cs[7] = c1.w;
+        sn[0] = s0.x; sn[1] = s0.y; sn[2] = s0.z; sn[3] = s0.w; sn[4] = s1.x; sn[5] = s1.y; sn[6] = s1.z; sn[7] = s1.w;
+    }
+    auto rope8 = [&](int row, uint32_t (&out)[4]) {  // the lane's 8 dims of a row, rotated, as 4 bf16 pairs
+        const uint4 av = *reinterpret_cast<const uint4*>(rawb + row * HS + d0);
+        const uint4 bv = *reinterpret_cast<const uint4*>(rawb + row * HS + dpart);
+        const uint32_t a[4] = {av.x, av.y, av.z, av.w}, bq[4] = {bv.x, bv.y, bv.z, bv.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            float o0 = bflo(bq[e]), o1 = bfhi(bq[e]);
+            if (lo) {
+                o0 = -o0;
+                o1 = -o1;
+            }
+            // x * cos + rotate_half(x) * sin: both products and the sum rounded separately (no FMA), as the reference's promoted ops
+            const float r0 = __fadd_rn(__fmul_rn(bflo(a[e]), cs[2 * e]), __fmul_rn(o0, sn[2 * e]));
+            const float r1 = __fadd_rn(__fmul_rn(bfhi(a[e]), cs[2 * e + 1]), __fmul_rn(o1, sn[2 * e + 1]));
+            const uint32_t pk = (uint32_t)f2bf(r0) | ((uint32_t)f2bf(r1) << 16);
+            out[e] = rot ? pk : a[e];
+        }
     };
     const float scale = 1.0f / sqrtf((float)HS);
     float qf[HQ][8];
     uint32_t knew[4], vnew[4];
+    rope8(HQ, knew);
+    {
+        const uint4 vv = *reinterpret_cast<const uint4*>(rawb + (HQ + 1) * HS + d0);
+        vnew[0] = vv.x; vnew[1] = vv.y; vnew[2] = vv.z; vnew[3] = vv.w;
+    }
 #pragma unroll
-    for (int e = 0; e < 8; e += 2) {
-        knew[e >> 1] = (uint32_t)roped(HQ, dl * 8 + e) | ((uint32_t)roped(HQ, dl * 8 + e + 1) << 16);
-        vnew[e >> 1] = raw[((HQ + 1) * HS + dl * 8 + e) >> 1];
+    for (int h = 0; h < HQ; ++h) {
+        uint32_t qp[4];
+        rope8(h, qp);
 #pragma unroll
-        for (int h = 0; h < HQ; ++h) {
-            qf[h][e] = bf2f(roped(h, dl * 8 + e)) * scale;
-            qf[h][e + 1] = bf2f(roped(h, dl * 8 + e + 1)) * scale;
+        for (int e = 0; e < 4; ++e) {
+            qf[h][2 * e] = bflo(qp[e]) * scale;
+            qf[h][2 * e + 1] = bfhi(qp[e]) * scale;
         }
     }
     const int slot_new = c.pos % st.S;
@@ -606,7 +747,7 @@ __device__ __forceinline__ void eng_attn(const EngState& st, const EngCtx& c, En
     }
     for (int u = w.cw; u < ky.nunits; u += ENG_NC) {
         const int seq = w.seq + (u >> 3);
-        eng_wait_full(st, c, seq);
+        eng_wait_full(st, c, w, seq);
         const unsigned char* slot = c.ring + (seq % ENG_NSLOT) * ENG_SLOT_BYTES + (u & 7) * 2048;
         uint4 kv = *reinterpret_cast<const uint4*>(slot + c.lane * 16);
         uint4 vv = *reinterpret_cast<const uint4*>(slot + 1024 + c.lane * 16);
@@ -641,6 +782,7 @@ __device__ __forceinline__ void eng_attn(const EngState& st, const EngCtx& c, En
         eng_release(c, seq);
     }
     w.seq += (ky.nunits + 7) >> 3;
+    eng_stamp(st, c, w, k, 6);
     // ---- merge the key rows of the wave, then the waves of the CU
 #pragma unroll
     for (int h = 0; h < HQ; ++h) {
@@ -659,6 +801,7 @@ __device__ __forceinline__ void eng_attn(const EngState& st, const EngCtx& c, En
         }
     }
     eng_cbar(st, c, w);
+    eng_stamp(st, c, w, k, 7);
     if (w.cw == 0) {
 #pragma unroll
         for (int h = 0; h < HQ; ++h) {
@@ -678,38 +821,64 @@ __device__ __forceinline__ void eng_attn(const EngState& st, const EngCtx& c, En
             if (c.lane == 0) st_gran(pg + HS, __float_as_uint(M), c.epoch);
             if (c.lane == 1) st_gran(pg + HS + 1, __float_as_uint(L), c.epoch);
         }
-        if (ky.s == 0) {  // the group's leader merges the splits into the heads
+    }
+    if (ky.s == 0) {  // the group's leader CU merges the splits into the heads: every wave fetches a share of the partial states
+        const int cnt = HQ * st.nsplit * PW;  // the group's heads lie back to back
+        const uint64_t* pg = op->part + (int64_t)ky.g * HQ * st.nsplit * PW;
+        constexpr int NLD = (2 * 8 * PW + 63) / 64, NPW = (NLD + ENG_NC - 1) / ENG_NC;  // HQ <= 2, nsplit <= 8
+        if (!ENG_ATTN_GATE) {
+        } else if (w.cw == 0) {  // one poller per CU
+            (void)eng_gran_wait(st, c, pg + (cnt - 1), 0, true, 0x54000000u | (uint32_t)k);
+            if (c.lane == 0) lds_st(c.fx + EF_GATE2, (uint32_t)(k + 1));
+        } else {
+            eng_wait_lds_ge(st, c, EF_GATE2, (uint32_t)(k + 1), 0x55000000u | (uint32_t)k);
+        }
+        unsigned spins = 0;
+        for (;;) {  // flat sweep: every load in flight at once, repeated until every tag matches
+            uint64_t gv[NPW];
 #pragma unroll
-            for (int h = 0; h < HQ; ++h) {
-                const int cnt = st.nsplit * PW;
-                const uint64_t* pg = op->part + (int64_t)(ky.g * HQ + h) * st.nsplit * PW;
-                for (int t0 = 0; t0 < cnt; t0 += 64) {
-                    const int i = t0 + c.lane;
-                    const uint64_t* p = pg + min(i, cnt - 1);
-                    const uint32_t d = eng_gran_wait(st, c, p, ld_gran(p), i < cnt, 0x51000000u | (uint32_t)k);
-                    if (i < cnt) stage[i] = __uint_as_float(d);
-                }
-                lds_drain();
-                float M = -INFINITY;
-                for (int s = 0; s < st.nsplit; ++s) M = fmaxf(M, stage[s * PW + HS]);
-                float L = 0.f, y0 = 0.f, y1 = 0.f;
-                const int d0 = (2 * c.lane) % HS;
-                for (int s = 0; s < st.nsplit; ++s) {
-                    const float ms = stage[s * PW + HS];
-                    const float f = (ms == -INFINITY) ? 0.f : __expf(ms - M);
-                    L += stage[s * PW + HS + 1] * f;
-                    y0 += stage[s * PW + d0] * f;
-                    y1 += stage[s * PW + d0 + 1] * f;
-                }
-                const uint32_t pk = (uint32_t)f2bf(y0 / L) | ((uint32_t)f2bf(y1 / L) << 16);
-                if (c.lane < HS / 2)
-                    st_gran(reinterpret_cast<uint64_t*>(op->out) + (((int64_t)(ky.g * HQ + h) * HS) >> 1) + c.lane, pk, c.epoch);
-                lds_drain();
+            for (int t = 0; t < NPW; ++t) gv[t] = ld_gran(pg + min(64 * (w.cw + ENG_NC * t) + c.lane, cnt - 1));
+            bool ok = true;
+#pragma unroll
+            for (int t = 0; t < NPW; ++t) {
+                const int i = 64 * (w.cw + ENG_NC * t) + c.lane;
+                ok = ok && ((uint32_t)(gv[t] >> 32) == c.epoch || i >= cnt);
+                if (i < cnt) stage[i] = __uint_as_float((uint32_t)gv[t]);
             }
+            if (__all(ok)) break;
+            __builtin_amdgcn_s_sleep(2);
+            if ((++spins & 15u) == 0) {
+                if (eng_aborted(c)) break;
+                if (spins > ENG_SPINS_GLOBAL || ld_err(st) != 0) {
+                    eng_fail(st, c, 0x51000000u | (uint32_t)k);
+                    break;
+                }
+            }
+        }
+        eng_cbar(st, c, w);
+        if (w.cw < HQ) {  // one wave per head
+            const int h = w.cw;
+            const float* sg = stage + h * st.nsplit * PW;
+            float M = -INFINITY;
+            for (int sp = 0; sp < st.nsplit; ++sp) M = fmaxf(M, sg[sp * PW + HS]);
+            float L = 0.f, y0 = 0.f, y1 = 0.f;
+            const int dd = (2 * c.lane) % HS;
+            for (int sp = 0; sp < st.nsplit; ++sp) {
+                const float ms = sg[sp * PW + HS];
+                const float f = (ms == -INFINITY) ? 0.f : __expf(ms - M);
+                L += sg[sp * PW + HS + 1] * f;
+                y0 += sg[sp * PW + dd] * f;
+                y1 += sg[sp * PW + dd + 1] * f;
+            }
+            const uint32_t pk = (uint32_t)f2bf(y0 / L) | ((uint32_t)f2bf(y1 / L) << 16);
+            if (c.lane < HS / 2)
+                st_gran(reinterpret_cast<uint64_t*>(op->out) + (((int64_t)(ky.g * HQ + h) * HS) >> 1) + c.lane, pk, c.epoch);
         }
     }
     eng_cbar(st, c, w);  // the scratch is free again (the next op's input goes into this buffer)
     eng_stamp(st, c, w, k, 2);
+    if (st.dbg != nullptr && c.cu == 0 && w.cw == 0 && c.lane == 0) st.dbg[k * 8 + 3] = w.waited;
+    w.waited = 0;
 }
 
 template <int HS, int HQ>
@@ -721,6 +890,11 @@ __device__ __forceinline__ void eng_consumer(const EngState& st, const EngCtx& c
     w.bc = 0;
     w.best = -INFINITY;
     w.best_i = 0x7fffffff;
+    w.waited = 0;
+    w.gate_spins = 0;
+#pragma unroll
+    for (int i = 0; i < ENG_MAXG; ++i) w.nwv[i] = 0;
+    eng_prefetch_norm(st, c, w, 0);
     for (int k = 0; k < st.nops; ++k) {
         const EngOp opv = eng_fetch_op(st.ops, k);
         const EngOp* op = &opv;
@@ -890,7 +1064,7 @@ static int e4_shape(int N, int K, int dual, int* nblocks, int* nq) {
 }
 
 static int64_t eng_attn_scratch_bytes(int hs, int hq, int nsplit) {
-    return (int64_t)(hq + 2) * hs * 2 + (int64_t)(ENG_NC * hq + nsplit) * (hs + 2) * 4;
+    return (int64_t)(hq + 2) * hs * 2 + (int64_t)(ENG_NC + nsplit) * hq * (hs + 2) * 4;
 }
 
 }  // namespace parrot
@@ -943,7 +1117,7 @@ int parrot_eng_step(const parrot_eng_state_t* state_host, void* stream) {
     PARROT_UNSUPPORTED(st.q_per_kv == 1 || st.q_per_kv == 2, "stream engine: q_per_kv=%d not built (1, 2)", st.q_per_kv);
     PARROT_REQUIRE(st.n_groups >= 1 && st.nsplit >= 1 && st.nsplit <= 8 && st.n_groups * st.nsplit <= ENG_WGS,
                    "eng_step: n_groups * nsplit must fit the %d workgroups", ENG_WGS);
-    PARROT_REQUIRE(st.n_elem % 2 == 0 && st.n_elem >= 0 && st.n_elem <= st.hs && st.n_elem <= 128, "eng_step: bad n_elem");
+    PARROT_UNSUPPORTED(st.n_elem % 16 == 0 && st.n_elem >= 0 && st.n_elem <= st.hs && st.n_elem <= 128, "stream engine: rotary width %d must be a multiple of 16, at most the head size", st.n_elem);
     PARROT_REQUIRE(st.S >= 1 && st.V >= 1 && st.d >= 1, "eng_step: bad S / V / d");
     PARROT_REQUIRE(st.lds_buf0_bytes > 0 && st.lds_buf0_bytes % 16 == 0 && st.lds_buf1_bytes > 0 && st.lds_buf1_bytes % 16 == 0,
                    "eng_step: LDS buffer sizes must be positive multiples of 16");

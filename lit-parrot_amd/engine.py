@@ -59,7 +59,7 @@ class StreamEngine:
             return "not a sequential-residual RMSNorm / SwiGLU model"
         if c.head_size not in (64, 128) or c.q_per_kv not in (1, 2):
             return f"head size {c.head_size} / q_per_kv {c.q_per_kv}"
-        if c.n_query_groups > ENG_WGS or c.rope_n_elem % 2 or c.rope_n_elem > 128:
+        if c.n_query_groups > ENG_WGS or c.rope_n_elem % 16 or c.rope_n_elem > 128:
             return "query group count / rotary width"
         if c.n_embd % 8 or c.qkv_size % 8 or c.padded_vocab_size % 8 or c.intermediate_size % 4 or c.n_embd > 16384:
             return "row counts that do not fill the 8-row blocks"
@@ -69,7 +69,7 @@ class StreamEngine:
         b1 = lib.parrot_eng_lds_bytes(c.n_embd, 0, 0, 0)
         if b0 < 0 or b1 < 0:
             return _hip.last_error()
-        if 7 * 17 * 1024 + b0 + b1 + 8400 > 160 * 1024:
+        if 7 * 17 * 1024 + b0 + b1 + 8500 > 160 * 1024:
             return "activation vectors do not fit the LDS beside the weight ring"
         return None
 
@@ -155,8 +155,10 @@ class StreamEngine:
 
     def enable_stamps(self) -> torch.Tensor:
         """Diagnostic: let workgroup 0 record 100 MHz timestamps per op (enter, input ready, last unit done)."""
-        self.dbg = torch.zeros((self.n_ops * 4,), dtype=torch.int64, device=self.logits.device)
+        self.dbg = torch.zeros((self.n_ops * 8,), dtype=torch.int64, device=self.logits.device)
         self.state.dbg = ptr(self.dbg)
+        self.dbg_all = torch.zeros((self.n_ops * ENG_WGS * 2,), dtype=torch.int64, device=self.logits.device)
+        self.state.dbg_all = ptr(self.dbg_all)
         return self.dbg
 
     def step(self) -> torch.Tensor:
