@@ -38,9 +38,6 @@ namespace parrot {
 #ifndef ENG_ATTN_GATE
 #define ENG_ATTN_GATE 0
 #endif
-#ifndef ENG_NORM_AHEAD
-#define ENG_NORM_AHEAD 0
-#endif
 constexpr int ENG_WGS = PARROT_ENG_WGS;
 constexpr int ENG_NC = 15;                // consumer waves
 constexpr int ENG_THREADS = (ENG_NC + 1) * 64;
@@ -303,6 +300,18 @@ __device__ __forceinline__ void eng_loader(const EngState& st, const EngCtx& c) 
             st.dbg[k * 8 + 5] = (uint64_t)seq | ((uint64_t)pub << 32);
         }
         if (op->type == PARROT_ENG_GEMV) {
+            if (op->norm_kind != 0) {
+                // the norm's weights (K bf16, constants) ride the ring too: a plain load of them sat in front of the
+                // hand-off polls (vmcnt is in order) with an HBM miss of 1 - 2 us; every consumer wave reads its share
+                const int np = (op->K * 2 + 1023) >> 10;
+                const uint32_t target = acquire(np, k);
+                const unsigned dst = __builtin_amdgcn_readfirstlane(ring_lds + (unsigned)((seq % ENG_NSLOT) * ENG_SLOT_BYTES));
+                const int64_t last = (int64_t)op->K * 2 - 16;
+                for (int j = 0; j < np; ++j)
+                    eng_dma<false>(reinterpret_cast<const unsigned char*>(op->norm_w) + min((int64_t)j * 1024 + c.lane * 16, last),
+                                   dst + (unsigned)(j * 1024));
+                commit(target, np, ENG_NC);
+            }
             int b0, b1;
             eng_block_range(op->nblocks, c.cu, b0, b1);
             const int nq = op->nq, spb = (nq + 3) >> 2;
@@ -352,7 +361,6 @@ struct EngCons {
     int best_i;
     uint64_t waited;  // diagnostic: 100 MHz ticks this wave spent waiting for ring slots in the current op
     unsigned gate_spins;  // diagnostic: polls of the gather's first granule
-    uint32_t nwv[ENG_MAXG];  // this wave's share of the NEXT norm's weights (constants: fetched an op ahead, off the hand-off)
 };
 
 // barrier over the consumer waves (the loader never joins)
@@ -402,21 +410,6 @@ __device__ __forceinline__ uint32_t eng_gran_wait(const EngState& st, const EngC
     return (uint32_t)v;
 }
 
-// this wave's share of the weights of the norm in front of op k (if it has one) -> registers, requested an op ahead: the
-// loads are in order with the hand-off polls (vmcnt), so a 2 - 3 us HBM miss here would otherwise sit in front of them
-__device__ __forceinline__ void eng_prefetch_norm(const EngState& st, const EngCtx& c, EngCons& w, int k) {
-    if (k >= st.nops) return;
-    const EngOp op = eng_fetch_op(st.ops, k);
-    if (op.type != PARROT_ENG_GEMV || op.norm_kind != 1) return;
-    glb_cu32_t nw = (glb_cu32_t)op.norm_w;
-    const int npairs = op.K >> 1, ngr = (op.K + 127) >> 7;
-#pragma unroll
-    for (int i = 0; i < ENG_MAXG; ++i) {
-        const int g = w.cw + ENG_NC * i;
-        if (g < ngr) w.nwv[i] = nw[min(64 * g + c.lane, npairs - 1)];
-    }
-}
-
 // ---- input vector of a GEMV op -> LDS activation buffer (normalised bf16, per-group sums)
 __device__ __forceinline__ void eng_gather(const EngState& st, const EngCtx& c0, EngCons& w, const EngOp* op, int k) {
     EngCtx c = c0;
@@ -427,14 +420,7 @@ __device__ __forceinline__ void eng_gather(const EngState& st, const EngCtx& c0,
     const int ngr_pad = op->nq * 8;
     unsigned char* buf = op->buf ? c.buf1 : c.buf0;
     float* xs = reinterpret_cast<float*>(c.fx + EF_XS) + op->buf * 128;
-    uint32_t xv[ENG_MAXG], nwv[ENG_MAXG];
-#pragma unroll
-    for (int i = 0; i < ENG_MAXG; ++i) nwv[i] = w.nwv[i];  // fetched while the previous op ran (eng_prefetch_norm)
-    if (!ENG_NORM_AHEAD) {
-        eng_prefetch_norm(st, c, w, k);
-#pragma unroll
-        for (int i = 0; i < ENG_MAXG; ++i) nwv[i] = w.nwv[i];
-    }
+    uint32_t xv[ENG_MAXG];
     if (op->in_embedding) {
         glb_cu32_t e32 = (glb_cu32_t)c.emb;
 #pragma unroll
@@ -506,6 +492,11 @@ __device__ __forceinline__ void eng_gather(const EngState& st, const EngCtx& c0,
         for (int i = 0; i < ENG_NC; ++i) tot += reinterpret_cast<float*>(c.fx + EF_STAT)[i];
         r = norm_scale(na, tot);
     }
+    const unsigned char* nslot = c.ring;
+    if (na.kind == 1) {  // the norm weights arrived through the ring (one slot, in front of the op's weights)
+        eng_wait_full(st, c, w, w.seq);
+        nslot = c.ring + (w.seq % ENG_NSLOT) * ENG_SLOT_BYTES;
+    }
 #pragma unroll
     for (int i = 0; i < ENG_MAXG; ++i) {
         const int g = w.cw + ENG_NC * i;
@@ -514,12 +505,19 @@ __device__ __forceinline__ void eng_gather(const EngState& st, const EngCtx& c0,
             if (g < ngr) {
                 o = xv[i];
                 const int pr = 64 * g + c.lane;
-                if (na.kind == 1) o = pr < npairs ? norm_apply(o, nwv[i], 0u, 1, 0.f, r) : 0u;
+                if (na.kind == 1) {
+                    const uint32_t nwp = *reinterpret_cast<const uint32_t*>(nslot + min(pr, npairs - 1) * 4);
+                    o = pr < npairs ? norm_apply(o, nwp, 0u, 1, 0.f, r) : 0u;
+                }
             }
             *reinterpret_cast<uint32_t*>(buf + g * ENG_GROUP_STRIDE + c.lane * 4) = o;
             const float t = wave_sum_to_lane63(bflo(o) + bfhi(o));
             if (c.lane == 63) xs[g] = t;
         }
+    }
+    if (na.kind == 1) {
+        eng_release(c, w.seq);
+        w.seq += 1;
     }
     eng_cbar(st, c, w);
 }
@@ -532,7 +530,6 @@ __device__ __forceinline__ void eng_gemv(const EngState& st, const EngCtx& c0, E
     asm volatile("" : "+v"(c.lane));
     if (w.cw == 0 && c.lane == 0) lds_st(c.fx + EF_CUR, (uint32_t)k);
     eng_stamp(st, c, w, k, 1);
-    if (ENG_NORM_AHEAD) eng_prefetch_norm(st, c, w, k + 1);
     int b0, b1;
     eng_block_range(op->nblocks, c.cu, b0, b1);
     const int nq = op->nq, spb = (nq + 3) >> 2;
@@ -892,9 +889,6 @@ __device__ __forceinline__ void eng_consumer(const EngState& st, const EngCtx& c
     w.best_i = 0x7fffffff;
     w.waited = 0;
     w.gate_spins = 0;
-#pragma unroll
-    for (int i = 0; i < ENG_MAXG; ++i) w.nwv[i] = 0;
-    eng_prefetch_norm(st, c, w, 0);
     for (int k = 0; k < st.nops; ++k) {
         const EngOp opv = eng_fetch_op(st.ops, k);
         const EngOp* op = &opv;

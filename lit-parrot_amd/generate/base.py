@@ -52,6 +52,8 @@ class DecodeSession:
         self.eng = None
         if engine is None:
             engine = ENGINE_DEFAULT
+        if engine == "auto":
+            engine = max_seq_length >= ENGINE_AUTO_MIN_WINDOW
         if engine and StreamEngine.supported(model) is None:
             self.eng = StreamEngine(model, self.tokens, self.pos, self.caches, max_seq_length, greedy)
 
@@ -109,7 +111,11 @@ class DecodeSession:
         return self.eng.logits[0] if self.eng is not None else self.ws.logits[0]
 
 
-ENGINE_DEFAULT = False  # the one-launch stream engine for the models it is built for (Llama-2 7B family, int4 g128)
+# The one-launch stream engine (engine.py) for the models it is built for (Llama-2 7B family, int4 g128).  Measured on
+# Llama-2-7B int4: its token time barely moves with the context (K/V rows stream through the same LDS ring
+# as the weights, on all 256 CUs), the multi-launch step's grows; they cross below 1k keys.  "auto" picks by window size.
+ENGINE_DEFAULT = "auto"
+ENGINE_AUTO_MIN_WINDOW = 1024
 
 
 def _session(model: GPT, max_seq_length: int, max_tokens: int, greedy: bool) -> DecodeSession:
