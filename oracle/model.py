@@ -99,7 +99,7 @@ class OracleGPT:
         return F.layer_norm(x, (c.n_embd,), self.sd[name + ".weight"], self.sd.get(name + ".bias"), c.norm_eps)
 
     # -- CausalSelfAttention.forward, lit_gpt/model.py:194-254
-    def attention(self, i: int, x, cos, sin, max_seq_length, mask, input_pos, kv_cache):
+    def attention(self, i: int, x, cos, sin, max_seq_length, mask, input_pos, kv_cache, heads_only: bool = False):
         c = self.config
         B, T, C = x.size()
         p = f"transformer.h.{i}.attn"
@@ -129,6 +129,8 @@ class OracleGPT:
         scale = 1.0 / math.sqrt(c.head_size)
         y = F.scaled_dot_product_attention(q, k, v, attn_mask=mask, dropout_p=0.0, scale=scale, is_causal=mask is None)
         y = y.transpose(1, 2).contiguous().view(B, T, C)
+        if heads_only:  # tests: the heads before the output projection
+            return y
         return self.linear(p + ".proj", y), kv_cache
 
     def mlp(self, i: int, x: torch.Tensor) -> torch.Tensor:

@@ -6,21 +6,20 @@ Oracles, in order of authority:
      where the reference has nothing runnable (gptq grouped forward on a full model, LLM.int8) and for token-by-token
      greedy comparisons.
 
-Tolerances (north_star: logits within 1e-3 at bf16, 1e-2 at int4, greedy tokens equal at bf16).  A bf16 logit of
-magnitude ~0.5 has an ulp of 2^-9..2^-8 (0.002-0.004): the reference's own bf16 logits sit 0.006-0.013 (max) and
-~0.0015 (mean) away from its fp32 logits on these models.  Two correct bf16 pipelines that differ only in fp32
-summation order agree bit for bit until one intermediate lands on the other side of a rounding boundary (about one
-element in 2^15), after which everything downstream differs by an ulp or two — so an absolute 1e-3 bound between two
-bf16 results is below the resolution of the format.  What is asserted instead, per family:
-  (a) accuracy: |hip - ref_fp32| <= 1.5 x max / 1.25 x mean of |ref_bf16 - ref_fp32| (+ 1e-3 / 1e-4) — the HIP logits are as
-      close to the reference's exact answer as the reference's own bf16 run;
-  (b) distance: mean |hip - ref_bf16| <= 1.5 x mean |ref_bf16 - ref_fp32| (two independent roundings of the same exact
-      value are ~sqrt(2) of one error apart) and max <= 2 x max + 1e-3;
-  (c) with ``ops.RMSNORM_RSQRT_MODE = 1`` (the CPU-run reference's rsqrt rounding) the RMSNorm families
-      must sit clearly inside the reference's own error: mean distance <= 0.8 x its mean error.  (Measured: token row 0,
-      whose attention has a single key, is bit-identical in every family; later rows differ where torch's CPU
-      flash-attention rounds the softmax probabilities to bf16 before P.V while this kernel keeps them in fp32;
-      the MQA family, which torch runs through its fp32 math path, is bit-identical on every logit.)
+Tolerances (north_star: logits within 1e-3 at bf16, 1e-2 at int4, greedy tokens equal at bf16).  Two correct bf16
+pipelines that differ in fp32 summation order agree bit for bit until one intermediate lands on the other side of a
+rounding boundary, after which everything downstream differs by an ulp or two AT THE SCALE THE SUMS ROUND AT - the
+row's largest logits - whatever the size of the individual logit (a logit of 0.003 next to ones of 0.8 is a difference of
+large terms).  The bound is therefore stated PER LOGIT in two forms, with the smallest constants the measured distances
+support (tools/parity_table.py, table in DESIGN.md §6: max 3.00 row-ulp / k_ref 8.98 over all families and cases):
+  (a) |hip - ref_bf16| <= 1e-3 + k_row * ulp_bf16(max |ref| of the row), k_row = 3 (RMSNorm families, default rsqrt
+      rounding), 2.5 (RMSNorm families with the CPU-run reference's rsqrt rounding), 1.5 (LayerNorm
+      families); the MQA family (torch's fp32 math path on the CPU) must be BIT-IDENTICAL;
+  (b) for logits with |ref| >= 1/8: |hip - ref_bf16| <= 1e-3 + 9 * ulp_bf16(ref) (north_star's form; 9 is measured);
+  (c) accuracy: max |hip - ref_fp32| <= 1.25 x max |ref_bf16 - ref_fp32| + 1e-3 and the means likewise - the HIP logits are
+      as close to the reference's exact answer as the reference's own bf16 run;
+  (d) at least 15 % of the logits of every case bit-identical (measured 17 - 44 %).
+No tolerance here may be widened without the measured number beside it.
 """
 import numpy as np
 import pytest
@@ -44,15 +43,35 @@ def ulp_bf16(x: torch.Tensor) -> torch.Tensor:
     return torch.pow(2.0, torch.floor(torch.log2(x.abs().clamp_min(2.0 ** -100))) - 7)
 
 
-def check_bf16_logits(hip, ref_bf16, ref_f32, what, tight=False):
+def check_bf16_logits(hip, ref_bf16, ref_f32, what, k_row):
+    """Per-logit bounds (a) - (d) of the module docstring; k_row == 0 demands bit-identical logits."""
     hip = hip.detach().float().cpu()
     assert torch.isfinite(hip).all(), what
-    err_hip, err_ref, dist = (hip - ref_f32).abs(), (ref_bf16 - ref_f32).abs(), (hip - ref_bf16).abs()
-    assert float(err_hip.max()) <= 1.5 * float(err_ref.max()) + 1e-3, f"{what}: max error {float(err_hip.max()):.4g} vs reference's {float(err_ref.max()):.4g}"
+    dist = (hip - ref_bf16).abs()
+    if k_row == 0:
+        assert float(dist.max()) == 0.0, f"{what}: {int((dist != 0).sum())} logits differ from the reference's (expected bit-identical)"
+        return 1.0
+    ulp_row = ulp_bf16(ref_bf16.abs().amax(dim=-1, keepdim=True))
+    bad = dist > 1e-3 + k_row * ulp_row
+    assert not bool(bad.any()), (f"{what}: {int(bad.sum())} logits further than 1e-3 + {k_row} row-ulp from the reference's "
+                                 f"(worst {float((dist / ulp_row).max()):.2f} row-ulp, |d| {float(dist.max()):.4g})")
+    big = ref_bf16.abs() >= 0.125
+    bad = (dist > 1e-3 + 9 * ulp_bf16(ref_bf16)) & big
+    assert not bool(bad.any()), f"{what}: {int(bad.sum())} logits with |ref| >= 1/8 further than 1e-3 + 9 ulp(ref)"
+    err_hip, err_ref = (hip - ref_f32).abs(), (ref_bf16 - ref_f32).abs()
+    assert float(err_hip.max()) <= 1.25 * float(err_ref.max()) + 1e-3, f"{what}: max error {float(err_hip.max()):.4g} vs reference's {float(err_ref.max()):.4g}"
     assert float(err_hip.mean()) <= 1.25 * float(err_ref.mean()) + 1e-4, f"{what}: mean error {float(err_hip.mean()):.4g} vs reference's {float(err_ref.mean()):.4g}"
-    assert float(dist.max()) <= 2 * float(err_ref.max()) + 1e-3, f"{what}: max distance {float(dist.max()):.4g}"
-    assert float(dist.mean()) <= (0.8 if tight else 1.5) * float(err_ref.mean()) + 1e-5, f"{what}: mean distance {float(dist.mean()):.4g} vs {float(err_ref.mean()):.4g}"
-    return float((dist == 0).float().mean())
+    same = float((dist == 0).float().mean())
+    assert same >= 0.15, f"{what}: only {same:.3f} of the logits bit-identical"
+    return same
+
+
+def k_row_for(cfg, rsqrt_mode):
+    if cfg.n_query_groups == 1 and cfg.n_head > 1:
+        return 0  # MQA: torch runs its fp32 math attention on the CPU; this path keeps P in fp32 too -> identical bits
+    if cfg._norm_class == "LayerNorm":
+        return 1.5
+    return 2.5 if rsqrt_mode else 3
 
 
 def hip_model(cfg, sd, mode=None):
@@ -73,15 +92,15 @@ def cpu_rsqrt_mode():
 
 @pytest.mark.parametrize("name", [n for n in TINY if "llama" in n])
 def test_bf16_logits_rmsnorm_families_in_cpu_rsqrt_mode(golden_dir, name, cpu_rsqrt_mode):
-    """(c): with the CPU-run reference's rsqrt rounding the RMSNorm models track the golden logits as closely as the
-    LayerNorm ones do (most logits bit-identical)."""
-    test_bf16_logits_match_the_reference(golden_dir, name, tight=True)
+    """With the CPU-run reference's rsqrt rounding the RMSNorm models sit within 2.5 row-ulp of the golden logits."""
+    test_bf16_logits_match_the_reference(golden_dir, name, rsqrt_mode=1)
 
 
 @pytest.mark.parametrize("name", TINY)
-def test_bf16_logits_match_the_reference(golden_dir, name, tight=False):
+def test_bf16_logits_match_the_reference(golden_dir, name, rsqrt_mode=0):
     g = np.load(golden_dir / f"model_{name}.npz")
     cfg = Config.from_name(name)
+    tight = k_row_for(cfg, rsqrt_mode)
     sd = {k: v.to(BF) for k, v in synthetic_state_dict(cfg, MODEL_SEED, perturb=True).items()}
     model = hip_model(cfg, sd)
     tokens = torch.from_numpy(g["tokens"])
@@ -94,16 +113,85 @@ def test_bf16_logits_match_the_reference(golden_dir, name, tight=False):
         pos = torch.arange(T_PROMPT, device=DEV)
         check_bf16_logits(model(prompt.view(1, -1), MAX_SEQ, pos)[0], t("prefill_bf16"), t("prefill_f32"), f"{name} prefill", tight)
         assert len(model.kv_caches) == cfg.n_layer and model.kv_caches[0][0].shape == (1, cfg.n_query_groups, MAX_SEQ, cfg.head_size)
+        rows = []
         for i in range(4):
             pos = pos[-1:] + 1
-            check_bf16_logits(model(forced[i].view(1, 1), MAX_SEQ, pos)[0], t("decode_bf16")[i:i + 1], t("decode_f32")[i:i + 1], f"{name} decode {i}")
+            rows.append(model(forced[i].view(1, 1), MAX_SEQ, pos)[0])
+        check_bf16_logits(torch.cat(rows), t("decode_bf16"), t("decode_f32"), f"{name} decode", tight)
         # sliding window (max_seq_length 10, positions up to 14): ring slots vs the reference's rolled cache
         model.reset_cache()
         pos = torch.arange(T_PROMPT, device=DEV)
         model(prompt.view(1, -1), WINDOW, pos)
+        rows = []
         for i in range(8):
             pos = pos[-1:] + 1
-            check_bf16_logits(model(forced[i].view(1, 1), WINDOW, pos)[0], t("window_bf16")[i:i + 1], t("window_f32")[i:i + 1], f"{name} window {i}")
+            rows.append(model(forced[i].view(1, 1), WINDOW, pos)[0])
+        check_bf16_logits(torch.cat(rows), t("window_bf16"), t("window_f32"), f"{name} window", tight)
+
+
+@pytest.mark.parametrize("name", ["tiny-llama", "tiny-llama-gqa", "tiny-llama-hs128"])
+def test_where_the_reference_bits_are_left(name, cpu_rsqrt_mode):
+    """Which op of a non-MQA family stops being bit-identical to the reference (CPU rsqrt rounding): block 0 of a 7-token
+    prompt, every op fed THE REFERENCE'S OWN input (oracle = the reference bit for bit) so that each is judged alone.
+      embedding                     identical;
+      norm_1 + QKV linear           identical up to fp32 summation order: a few outputs per thousand land on the other
+                                    side of a bf16 rounding boundary (1 ulp), on any row;
+      RoPE + attention              row 0 (a single key) identical; from row 1 on the heads differ by construction: torch's
+                                    CPU flash kernel rounds the softmax probabilities to bf16 before P.V, this path keeps them
+                                    in fp32 (DESIGN.md §6.3) - the first systematic difference;
+      proj + residual, norm_2 + MLP identical up to summation order again.
+    The fractions are printed (pytest -s) and quoted in DESIGN.md §6."""
+    from lit_parrot_amd import ops
+    from lit_parrot_amd._hip import EPI_RESIDUAL
+    from lit_parrot_amd.model import _linear
+
+    cfg = Config.from_name(name)
+    tokens = synthetic_prompt(cfg, T_PROMPT, 21)
+    sd = {k: v.to(BF) for k, v in synthetic_state_dict(cfg, MODEL_SEED, perturb=True).items()}
+    model = hip_model(cfg, sd)
+    oracle = om.OracleGPT(cfg, sd)
+    T = T_PROMPT
+    same = lambda a, b: float((a.cpu() == b).float().mean())  # noqa: E731
+    with torch.no_grad():
+        # the reference, op by op (lit_gpt/model.py:99, :167-180, :194-232)
+        x_ref = sd["transformer.wte.weight"][tokens].view(1, T, -1)
+        n1 = oracle.norm("transformer.h.0.norm_1", x_ref)
+        qkv_ref = oracle.linear("transformer.h.0.attn.attn", n1)
+        cos, sin = om.rope_tables(cfg.block_size, cfg.rope_n_elem, BF, math_dtype=BF)
+        heads_ref = oracle.attention(0, n1, cos[:T], sin[:T], T, None, None, None, heads_only=True)
+        xa_ref = x_ref + oracle.linear("transformer.h.0.attn.proj", heads_ref)
+        xb_ref = xa_ref + oracle.mlp(0, oracle.norm("transformer.h.0.norm_2", xa_ref))
+        # the HIP ops, each on the reference's input
+        ws = model.workspace(T, DEV)
+        if model.rope_cache is None:
+            model.rope_cache = model.build_rope_cache(tokens.to(DEV))
+        blk = model.transformer.h[0]
+        ops.embedding(model.transformer.wte.weight.data, tokens.to(DEV), None, T, ws.x)
+        assert torch.equal(ws.x.cpu(), x_ref[0]), "embedding"
+        _linear(blk.attn.attn, ws.x, ws.qkv, norm=blk.norm_1)
+        f_qkv = same(ws.qkv, qkv_ref[0])
+        assert f_qkv >= 0.98 and float((ws.qkv.cpu().float() - qkv_ref[0].float()).abs().max()) <= 2 ** -8 * max(1.0, float(qkv_ref.float().abs().max()))
+        ws.qkv.copy_(qkv_ref[0].to(DEV))
+        kc, vc = (torch.zeros((cfg.n_query_groups, T, cfg.head_size), dtype=BF, device=DEV) for _ in range(2))
+        nsplit = ops.attn_nsplit(cfg.n_query_groups, T, cfg.q_per_kv, T)
+        rc, rs = model.rope_cache
+        ops.rope_kvappend(ws.qkv, rc, rs, cfg.rope_n_elem, ws.zero_pos, cfg.n_query_groups, cfg.q_per_kv, cfg.head_size, T, ws.q, kc, vc, False)
+        ops.attn_decode(ws.q, ws.zero_pos, kc, vc, cfg.n_query_groups, cfg.q_per_kv, cfg.head_size, T, nsplit, ws.attn_ws(cfg, nsplit), ws.y)
+        heads = ws.y.cpu()
+        f_rows = [float((heads[r] == heads_ref[0, r]).float().mean()) for r in range(T)]
+        assert f_rows[0] == 1.0, "attention row 0 (a single key) must be bit-identical"
+        assert min(f_rows[1:]) < 1.0, "expected the P.V rounding difference from row 1 on"
+        assert float((heads.float() - heads_ref[0].float()).abs().max()) <= 2 ** -7 * max(1.0, float(heads_ref.float().abs().max()))
+        ws.y.copy_(heads_ref[0].to(DEV))
+        ws.x.copy_(x_ref[0].to(DEV))
+        _linear(blk.attn.proj, ws.y, ws.t, epilogue=EPI_RESIDUAL, residual=ws.x)
+        f_proj = same(ws.t, xa_ref[0])
+        ws.x.copy_(xa_ref[0].to(DEV))
+        blk.mlp.run_rows(ws, ws.x, residual=ws.x, out=ws.t, norm=blk.norm_2)
+        f_mlp = same(ws.t, xb_ref[0])
+        assert f_proj >= 0.98 and f_mlp >= 0.95
+    print(f"{name}: bit-identical share per op on the reference's input - norm_1+QKV {f_qkv:.4f}, attention rows "
+          f"{[round(f, 3) for f in f_rows]}, proj+residual {f_proj:.4f}, norm_2+MLP+residual {f_mlp:.4f}")
 
 
 @pytest.mark.parametrize("name", ["tiny-llama", "tiny-neox", "tiny-falcon-gqa"])
@@ -200,6 +288,47 @@ def test_greedy_generate_token_for_token(name):
     finally:
         gb.DecodeSession.__init__ = orig
     assert torch.equal(y, y3), "hipGraph replay and eager launches disagree"
+
+
+def test_pythia160m_greedy_64_tokens_against_the_golden_run(golden_dir):
+    """BASELINE.json configs[0] on the GPU: Pythia-160M, the golden run's 128-token prompt, 64 greedy tokens at bf16.
+    Judge: the oracle at bf16 (bit-exact restatement of the reference, tests/test_oracle_golden.py), teacher-forced with
+    the HIP tokens.  Wherever the oracle's top-2 margin exceeds 2 bf16 ulp the HIP token must BE the arg-max; inside that
+    margin it must be one of the (near-)maxima.  The reference's own fp32 token sequence (tests/golden/generate.npz) is
+    followed until the first step whose bf16 margin is that small."""
+    g = np.load(golden_dir / "generate.npz")
+    cfg = Config.from_name("pythia-160m")
+    sd = {k: v.to(BF) for k, v in synthetic_state_dict(cfg, 1234).items()}
+    model = hip_model(cfg, sd)
+    prompt = torch.from_numpy(g["prompt"])
+    golden = torch.from_numpy(g["tokens"])
+    T, N = 128, 64
+    y = L.generate(model, prompt.to(DEV), T + N, T + N, temperature=1.0, top_k=1).cpu()
+    assert y.shape == (T + N,) and torch.equal(y[:T], prompt)
+    oracle = om.OracleGPT(cfg, sd)
+    strict = close = 0
+    first_close = None
+    with torch.no_grad():
+        pos = torch.arange(T)
+        logits = oracle(y[:T].view(1, -1), T + N, pos)[0, -1].float()
+        for i in range(N):
+            tok = int(y[T + i])
+            top2 = logits.topk(2).values
+            margin, ulp = float(top2[0] - top2[1]), float(ulp_bf16(top2[0]))
+            if margin > 2 * ulp:
+                assert tok == int(logits.argmax()), f"token {i}: {tok} is not the arg-max {int(logits.argmax())} (margin {margin / ulp:.1f} ulp)"
+                strict += 1
+            else:
+                assert float(logits[tok]) >= float(top2[0]) - 2 * ulp, f"token {i}: {tok} is not a (near-)argmax"
+                close += 1
+                first_close = i if first_close is None else first_close
+            if i + 1 < N:
+                pos = pos[-1:] + 1
+                logits = oracle(y[T + i].view(1, 1), T + N, pos)[0, -1].float()
+    assert strict >= N // 2, (strict, close)
+    agree = int((y[T:] == golden[T:T + N]).long().cumprod(0).sum())  # tokens shared with the fp32 golden run, from the start
+    assert agree >= (N if first_close is None else first_close), (agree, first_close)
+    print(f"pythia-160m bf16 greedy: {strict} strict arg-max steps, {close} inside 2 ulp, {agree} leading tokens equal to the fp32 golden run")
 
 
 def test_generate_eos_and_sampling_paths():
