@@ -124,14 +124,17 @@ int parrot_bf16_gemm(const void* W, const void* W2, const void* x, int ldx, int 
                      const parrot_norm_t* norm, void* workspace, void* stream);
 
 /* ---- LLM.int8 (quantize/bnb.py:18-60; arithmetic = bitsandbytes MatMul8bitLt) ----
- * quantize rows of a bf16/fp16-valued weight: CB = rne(127*W/absmax_row), SCB = absmax_row (fp32) */
-int parrot_w8_quantize_rows(const void* W_bf16, int N, int K, void* CB_int8, void* SCB_f32, void* stream);
-/* activation prep per token row: fp16-round x, mark |x| >= threshold as outliers
- * (kept in 16-bit, zero in the int8 copy), absmax-quantise the rest.
- * xq int8 [M][K]; xout fp32 [M][K] (the outlier values, 0 elsewhere); sca fp32 [M]; nout int32 [M];
- * oidx int32 [M][K]: the first nout[m] entries of row m list its outlier columns */
+ * quantize the rows of a checkpoint weight as `double_quant(weight.contiguous().half())` does (quantize/bnb.py:54-60): the value
+ * is first rounded to fp16 whatever its dtype - w_dtype 0: bf16, 1: fp16, 2: fp32 -, CB = rne(127*W16/absmax_row), SCB = absmax_row */
+int parrot_w8_quantize_rows(const void* W, int w_dtype, int N, int K, void* CB_int8, void* SCB_f32, void* stream);
+/* activation prep of one call (its M token rows): fp16-round x; entries with |x| >= threshold are outliers (zero in the int8
+ * copy, excluded from their row's absmax); the OUTLIER COLUMNS are those with an outlier in any row of the call (LLM.int8's
+ * feature dimensions; bitsandbytes MatMul8bitLt: unique(colidx)) and are cleared in the int8 copy of every row.
+ * xq int8 [M][K]; xout fp32 [M][K]: the fp16 activations (readers use the listed columns only); sca fp32 [M]; nout int32 [M];
+ * oidx int32 [M][K]: the first nout[m] entries of row m list the outlier columns (for M > 1 the same ascending list in every
+ * row); colflag: K int32 of scratch, needed when M > 1 */
 int parrot_w8_prep_act(const void* x, int ldx, int M, int K, float threshold, void* xq, void* xout,
-                       void* sca, void* nout, void* oidx, const parrot_norm_t* norm, void* stream);
+                       void* sca, void* nout, void* oidx, void* colflag, const parrot_norm_t* norm, void* stream);
 /* out = epilogue(cast_bf16(fp16(fp16(C32*SCA*SCB/127^2 + bias) + fp16(outlier_part)))).
  * For PARROT_EPI_SWIGLU the second weight (fc_2) follows the first in the same buffers:
  * CB holds 2N rows ([fc_1; fc_2]) and SCB 2N scales. */

@@ -72,8 +72,8 @@ SIGNATURES = {
     "parrot_w4_gemm": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _np, _vp, _vp]),
     "parrot_bf16_gemv": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp, _i, _vp, _i, _i, _i, _i, _np, _vp]),
     "parrot_bf16_gemm": (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp, _i, _vp, _i, _i, _i, _i, _np, _vp, _vp]),
-    "parrot_w8_quantize_rows": (_i, [_vp, _i, _i, _vp, _vp, _vp]),
-    "parrot_w8_prep_act": (_i, [_vp, _i, _i, _i, _f, _vp, _vp, _vp, _vp, _vp, _np, _vp]),
+    "parrot_w8_quantize_rows": (_i, [_vp, _i, _i, _i, _vp, _vp, _vp]),
+    "parrot_w8_prep_act": (_i, [_vp, _i, _i, _i, _f, _vp, _vp, _vp, _vp, _vp, _vp, _np, _vp]),
     "parrot_w8_gemv": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _vp, _i, _i, _i, _i, _vp]),
     "parrot_w8_gemm_workspace_bytes": (_i64, [_i, _i, _i, _i]),
     "parrot_w8_gemm": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp, _vp, _i, _vp, _i, _i, _i, _i, _vp, _vp]),

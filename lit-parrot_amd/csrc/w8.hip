@@ -28,17 +28,23 @@ __device__ __forceinline__ float block_max_256(float v, float* sh) {
     return fmaxf(fmaxf(sh[0], sh[1]), fmaxf(sh[2], sh[3]));
 }
 
+// the checkpoint value as the reference quantises it: `weight.contiguous().half()` (quantize/bnb.py:54) whatever the dtype
+__device__ __forceinline__ float w8_as_half(bf16_t v) { return rhalf(bf2f(v)); }
+__device__ __forceinline__ float w8_as_half(__half v) { return __half2float(v); }
+__device__ __forceinline__ float w8_as_half(float v) { return rhalf(v); }
+
 // one workgroup (256 threads) per weight row
+template <typename T>
 __global__ void __launch_bounds__(256)
-w8_quantize_rows_kernel(const bf16_t* __restrict__ W, int K, int8_t* __restrict__ CB, float* __restrict__ SCB) {
+w8_quantize_rows_kernel(const T* __restrict__ W, int K, int8_t* __restrict__ CB, float* __restrict__ SCB) {
     __shared__ float sh[4];
-    const bf16_t* w = W + (int64_t)blockIdx.x * K;
+    const T* w = W + (int64_t)blockIdx.x * K;
     float mx = 0.f;
-    for (int k = threadIdx.x; k < K; k += 256) mx = fmaxf(mx, fabsf(rhalf(bf2f(w[k]))));
+    for (int k = threadIdx.x; k < K; k += 256) mx = fmaxf(mx, fabsf(w8_as_half(w[k])));
     mx = block_max_256(mx, sh);
     const float inv = mx > 0.f ? __fdiv_rn(127.0f, mx) : 0.f;  // correctly rounded, like the host oracle
     for (int k = threadIdx.x; k < K; k += 256)
-        CB[(int64_t)blockIdx.x * K + k] = (int8_t)rintf(__fmul_rn(rhalf(bf2f(w[k])), inv));
+        CB[(int64_t)blockIdx.x * K + k] = (int8_t)rintf(__fmul_rn(w8_as_half(w[k]), inv));
     if (threadIdx.x == 0) SCB[blockIdx.x] = mx;
 }
 
@@ -156,7 +162,7 @@ w8_prep_act_kernel(const bf16_t* __restrict__ x, int ldx, int K, float threshold
                 const bool outlier = threshold > 0.f && fabsf(a[i][e]) >= threshold;
                 const int qv = outlier ? 0 : (int)rintf(__fmul_rn(a[i][e], inv));
                 q8[e >> 2] |= (uint32_t)(qv & 0xff) << (8 * (e & 3));
-                o8[e] = outlier ? a[i][e] : 0.f;
+                o8[e] = a[i][e];  // every element: the union pass of a multi-row call needs the non-outliers of outlier columns too
                 if (outlier) oidx[(int64_t)m * K + slot++] = c * 8 + e;
             }
             *reinterpret_cast<uint2*>(xq + (int64_t)m * K + (int64_t)c * 8) = make_uint2(q8[0], q8[1]);
@@ -169,6 +175,48 @@ w8_prep_act_kernel(const bf16_t* __restrict__ x, int ldx, int K, float threshold
         sca[m] = mx;
         nout[m] = total;
     }
+}
+
+// ---- multi-row calls: LLM.int8's outliers are feature DIMENSIONS of the call (arXiv:2208.07339 §3.2; bitsandbytes MatMul8bitLt:
+// idx = unique(coo_tensorA.colidx), CA[:, idx] = 0, subA = A[:, idx]): a column with an outlier in ANY row leaves the int8 product of
+// EVERY row and goes through the 16-bit product for every row.  Pass 1, one thread per column: flag, and clear the column in xq.
+__global__ void __launch_bounds__(256)
+w8_union_cols_kernel(const float* __restrict__ xout, int8_t* __restrict__ xq, int32_t* __restrict__ colflag, int M, int K, float threshold) {
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    if (k >= K) return;
+    bool any = false;
+    for (int m = 0; m < M; ++m) any = any || fabsf(xout[(int64_t)m * K + k]) >= threshold;
+    colflag[k] = any ? 1 : 0;
+    if (any)
+        for (int m = 0; m < M; ++m) xq[(int64_t)m * K + k] = 0;
+}
+// Pass 2, one workgroup per row: the ascending list of flagged columns becomes the row's outlier list (the same for every row)
+__global__ void __launch_bounds__(1024)
+w8_union_lists_kernel(const int32_t* __restrict__ colflag, int32_t* __restrict__ nout, int32_t* __restrict__ oidx, int K) {
+    __shared__ int scan[16];
+    const int m = blockIdx.x;
+    const int per = (K + 1023) / 1024;  // consecutive columns per thread: the list comes out ascending
+    const int k0 = threadIdx.x * per, k1 = min(K, k0 + per);
+    int local = 0;
+    for (int k = k0; k < k1; ++k) local += colflag[k];
+    int incl = local;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const int o = __shfl_up(incl, off, 64);
+        if ((int)(threadIdx.x & 63) >= off) incl += o;
+    }
+    if ((threadIdx.x & 63) == 63) scan[threadIdx.x >> 6] = incl;
+    __syncthreads();
+    int base = 0, total = 0;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) {
+        if (w < (int)(threadIdx.x >> 6)) base += scan[w];
+        total += scan[w];
+    }
+    int slot = base + incl - local;
+    for (int k = k0; k < k1; ++k)
+        if (colflag[k]) oidx[(int64_t)m * K + slot++] = k;
+    if (threadIdx.x == 0) nout[m] = total;
 }
 
 constexpr int kW8MaxSlabs = 8;  // K <= 8 * 4096
@@ -862,24 +910,37 @@ using namespace parrot;
 
 extern "C" {
 
-int parrot_w8_quantize_rows(const void* W_bf16, int N, int K, void* CB_int8, void* SCB_f32, void* stream) {
-    PARROT_REQUIRE(W_bf16 && CB_int8 && SCB_f32, "w8_quantize_rows: null pointer");
+int parrot_w8_quantize_rows(const void* W, int w_dtype, int N, int K, void* CB_int8, void* SCB_f32, void* stream) {
+    PARROT_REQUIRE(W && CB_int8 && SCB_f32, "w8_quantize_rows: null pointer");
     PARROT_REQUIRE(N >= 1 && K >= 1, "w8_quantize_rows: bad shape N=%d K=%d", N, K);
-    return launch(K_W8_QUANT_ROWS, w8_quantize_rows_kernel, dim3(N), dim3(256), 0, (hipStream_t)stream,
-                  (const bf16_t*)W_bf16, K, (int8_t*)CB_int8, (float*)SCB_f32);
+    PARROT_REQUIRE(w_dtype >= 0 && w_dtype <= 2, "w8_quantize_rows: w_dtype must be 0 (bf16), 1 (fp16) or 2 (fp32)");
+    hipStream_t st = (hipStream_t)stream;
+    if (w_dtype == 1)
+        return launch(K_W8_QUANT_ROWS, w8_quantize_rows_kernel<__half>, dim3(N), dim3(256), 0, st, (const __half*)W, K, (int8_t*)CB_int8, (float*)SCB_f32);
+    if (w_dtype == 2)
+        return launch(K_W8_QUANT_ROWS, w8_quantize_rows_kernel<float>, dim3(N), dim3(256), 0, st, (const float*)W, K, (int8_t*)CB_int8, (float*)SCB_f32);
+    return launch(K_W8_QUANT_ROWS, w8_quantize_rows_kernel<bf16_t>, dim3(N), dim3(256), 0, st, (const bf16_t*)W, K, (int8_t*)CB_int8, (float*)SCB_f32);
 }
 
 int parrot_w8_prep_act(const void* x, int ldx, int M, int K, float threshold, void* xq, void* xout, void* sca, void* nout,
-                       void* oidx, const parrot_norm_t* norm, void* stream) {
+                       void* oidx, void* colflag, const parrot_norm_t* norm, void* stream) {
     PARROT_REQUIRE(x && xq && xout && sca && nout && oidx, "w8_prep_act: null pointer");
+    PARROT_REQUIRE(M == 1 || colflag != nullptr, "w8_prep_act: a call with several rows needs the K-word column scratch");
     PARROT_REQUIRE(M >= 1 && K >= 1 && ldx >= K, "w8_prep_act: bad shape M=%d K=%d ldx=%d", M, K, ldx);
     PARROT_UNSUPPORTED(K % 8 == 0 && ldx % 8 == 0 && K <= kPrepThreads * 8 * kPrepV && aligned16(x),
                        "w8_prep_act: K=%d must be a multiple of 8 and <= %d, rows 16-byte aligned", K, kPrepThreads * 8 * kPrepV);
     NormArgs na;
     const int rc = make_norm_args(norm, K, &na);
     if (rc != PARROT_OK) return rc;
-    return launch(K_W8_PREP_ACT, w8_prep_act_kernel, dim3(M), dim3(kPrepThreads), 0, (hipStream_t)stream, (const bf16_t*)x, ldx,
-                  K, threshold, (int8_t*)xq, (float*)xout, (float*)sca, (int32_t*)nout, (int32_t*)oidx, na);
+    int rc2 = launch(K_W8_PREP_ACT, w8_prep_act_kernel, dim3(M), dim3(kPrepThreads), 0, (hipStream_t)stream, (const bf16_t*)x, ldx,
+                     K, threshold, (int8_t*)xq, (float*)xout, (float*)sca, (int32_t*)nout, (int32_t*)oidx, na);
+    if (rc2 != PARROT_OK || M == 1 || !(threshold > 0.f)) return rc2;
+    // several rows: the outlier columns are those of the whole call
+    rc2 = launch(K_W8_PREP_ACT, w8_union_cols_kernel, dim3((K + 255) / 256), dim3(256), 0, (hipStream_t)stream, (const float*)xout,
+                 (int8_t*)xq, (int32_t*)colflag, M, K, threshold);
+    if (rc2 != PARROT_OK) return rc2;
+    return launch(K_W8_PREP_ACT, w8_union_lists_kernel, dim3(M), dim3(1024), 0, (hipStream_t)stream, (const int32_t*)colflag,
+                  (int32_t*)nout, (int32_t*)oidx, K);
 }
 
 // CB / SCB may be followed by a second weight for the SWIGLU epilogue: pass them concatenated as

@@ -195,9 +195,10 @@ def w4c_linear(packed: torch.Tensor, code_words: torch.Tensor, code_f32: torch.T
 
 def w8_quantize_rows(weight: torch.Tensor, CB: torch.Tensor, SCB: torch.Tensor) -> None:
     N, K = weight.shape
-    if weight.dtype != torch.bfloat16 or not weight.is_contiguous():
-        raise ParrotHipError("w8_quantize_rows: weight must be contiguous bf16")
-    check(_hip.load().parrot_w8_quantize_rows(ptr(weight), N, K, ptr(CB), ptr(SCB), stream()), "parrot_w8_quantize_rows")
+    code = {torch.bfloat16: 0, torch.float16: 1, torch.float32: 2}.get(weight.dtype)
+    if code is None or not weight.is_contiguous():
+        raise ParrotHipError("w8_quantize_rows: weight must be contiguous bf16, fp16 or fp32")
+    check(_hip.load().parrot_w8_quantize_rows(ptr(weight), code, N, K, ptr(CB), ptr(SCB), stream()), "parrot_w8_quantize_rows")
 
 
 class W8Act:
@@ -210,6 +211,7 @@ class W8Act:
         self.sca = torch.empty((M,), dtype=torch.float32, device=device)
         self.nout = torch.empty((M,), dtype=torch.int32, device=device)
         self.oidx = torch.empty((M, K), dtype=torch.int32, device=device)  # compact outlier column list per row
+        self.colflag = torch.empty((K,), dtype=torch.int32, device=device) if M > 1 else None  # outlier columns of the call
 
 
 def w8_prep_act(x: torch.Tensor, threshold: float, act: W8Act, norm: Optional[Norm] = None) -> W8Act:
@@ -217,7 +219,7 @@ def w8_prep_act(x: torch.Tensor, threshold: float, act: W8Act, norm: Optional[No
     M, K = x.shape
     assert (M, K) == (act.M, act.K)
     check(_hip.load().parrot_w8_prep_act(ptr(x), x.stride(0), M, K, float(threshold), ptr(act.xq), ptr(act.xout),
-                                         ptr(act.sca), ptr(act.nout), ptr(act.oidx), _norm_arg(norm, K), stream()), "parrot_w8_prep_act")
+                                         ptr(act.sca), ptr(act.nout), ptr(act.oidx), ptr(act.colflag), _norm_arg(norm, K), stream()), "parrot_w8_prep_act")
     return act
 
 

@@ -42,7 +42,12 @@ class InferenceLinear8bitLt(torch.nn.Linear):
         if not torch.cuda.is_available():
             raise ParrotHipError("InferenceLinear8bitLt quantises on the GPU: no HIP device is visible")
         dev = weight.device if weight.is_cuda else torch.device("cuda", torch.cuda.current_device())
-        w = weight.detach().to(device=dev, dtype=torch.bfloat16).contiguous()
+        # the checkpoint's own precision goes to the kernel, which rounds to fp16 like the reference's `weight.contiguous().half()`
+        # (bnb.py:54): casting an fp16 / fp32 checkpoint to bf16 first would drop three mantissa bits before the quantiser
+        w = weight.detach().to(device=dev)
+        if w.dtype not in (torch.bfloat16, torch.float16, torch.float32):
+            w = w.float()
+        w = w.contiguous()
         CB = torch.empty(w.shape, dtype=torch.int8, device=dev)
         SCB = torch.empty((w.shape[0],), dtype=torch.float32, device=dev)
         ops.w8_quantize_rows(w, CB, SCB)

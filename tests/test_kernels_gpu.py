@@ -351,6 +351,23 @@ def test_w8_weight_quantisation_is_exact():
     ops.w8_quantize_rows(W.to(DEV), CB, SCB)
     cb, scb = o8.quantize_weight_rows(W)
     assert torch.equal(CB.cpu(), cb) and torch.equal(SCB.cpu(), scb)
+    # fp16 and fp32 checkpoints (Llama-2 HF weights are fp16): the reference quantises `weight.half()` (quantize/bnb.py:54), so
+    # values that bf16 cannot hold must reach the quantiser with their fp16 mantissa
+    for dt in (torch.float16, torch.float32):
+        Wd = (torch.randn(50, 352, generator=g) * 0.02).to(dt)
+        assert not torch.equal(Wd.to(BF).to(dt), Wd)
+        ops.w8_quantize_rows(Wd.to(DEV), CB, SCB)
+        cb, scb = o8.quantize_weight_rows(Wd)
+        assert torch.equal(CB.cpu(), cb) and torch.equal(SCB.cpu(), scb), dt
+        cb_bf, _ = o8.quantize_weight_rows(Wd.to(BF))
+        assert not torch.equal(cb_bf, cb), "the bf16 detour would have changed the int8 weights"
+    from lit_parrot_amd.quantize.bnb import InferenceLinear8bitLt
+
+    lin = InferenceLinear8bitLt(352, 50, bias=False)
+    Wd = (torch.randn(50, 352, generator=g) * 0.02)
+    lin.load_state_dict({"weight": Wd})
+    cb, scb = o8.quantize_weight_rows(Wd)
+    assert torch.equal(lin.weight.data.cpu(), cb) and torch.equal(lin.weight.SCB.cpu(), scb)
 
 
 @pytest.mark.parametrize("N,K", [(64, 256), (96, 4096), (40, 352), (16, 11008)])
@@ -360,14 +377,23 @@ def test_w8_linear_matches_oracle(N, K, outliers, M):
     g = gen(13)
     W = (torch.randn(N, K, generator=g) * 0.02).to(BF)
     x = torch.randn(M, K, generator=g).to(BF)
-    if outliers:  # force the mixed-precision decomposition: |x| >= 6 in a few columns
-        x[0, 3], x[0, K - 1], x[M - 1, 17] = 9.5, -7.25, 6.0
+    if outliers:  # force the mixed-precision decomposition: |x| >= 6 in a few columns, in different rows
+        x[0, 3], x[0, K - 1], x[M - 1, 17], x[M // 2, 40] = 9.5, -7.25, 6.0, -11.0
     bias = (torch.randn(N, generator=g) * 0.1).to(BF)
     cb, scb = o8.quantize_weight_rows(W)
     act = ops.w8_prep_act(x.to(DEV), 6.0, ops.W8Act(M, K, DEV))
-    ca, sca, xout = o8.quantize_act_rows(x, 6.0)
-    assert torch.equal(act.xq.cpu(), ca) and torch.equal(act.sca.cpu(), sca) and torch.equal(act.xout.cpu(), xout)
-    assert act.nout.cpu().tolist() == (xout != 0).sum(dim=1).tolist()
+    ca, sca, sub_a = o8.quantize_act_rows(x, 6.0)
+    # outlier COLUMNS of the whole call (LLM.int8's feature dimensions): cleared in every row's int8 copy, listed for every row
+    cols = (x.half().float().abs() >= 6.0).any(dim=0)
+    assert int(cols.sum()) == (4 if outliers else 0) or M == 1
+    assert torch.equal(act.xq.cpu(), ca) and torch.equal(act.sca.cpu(), sca)
+    assert torch.equal(act.xout.cpu()[:, cols], sub_a[:, cols]) and torch.equal(act.xout.cpu(), x.half().float())
+    listed = cols.nonzero().flatten().tolist()
+    for m in range(M):
+        n = int(act.nout[m])
+        assert sorted(act.oidx[m, :n].cpu().tolist()) == listed, m
+        if M > 1:
+            assert act.oidx[m, :n].cpu().tolist() == listed
     out = torch.empty((M, N), dtype=BF, device=DEV)
     ops.w8_linear(cb.to(DEV), scb.to(DEV), N, K, act, out, bias=bias.to(DEV))
     want = o8.linear(x, cb, scb, bias, 6.0)
