@@ -2,21 +2,25 @@
 """Decode benchmark of the HIP path (contract in the task statement; metric from BASELINE.json).
 
     python bench.py --gpus 1 --steps 256 --warmup 16
+    python bench.py --gpus 4                       (spawns its own replicas, one fresh process per GPU)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
-        bench.py --gpus N --steps K --warmup W
+        bench.py --gpus N --steps K --warmup W     (an external launcher works too)
 
 A *step* is one single-stream decode token of the workload (default: Llama-2-7B, GPTQ int4 g128, random-init
 synthetic weights of that architecture, 128-token synthetic prompt): one replay of the captured hipGraph.  With N > 1
-every rank is an independent replica on its own GPU with its own prompt (no collective on the data path —
-"replicas only"); the ranks only meet at the timing barriers.  ``value`` = tokens decoded by all ranks
-/ max over ranks of the wall time of the K steps.
+every replica is an independent process on its own GPU with its own prompt (seed 1234 + i) - "replicas only",
+DESIGN.md §5: there is NO collective and no RCCL anywhere.  Without an external launcher the parent process (which never
+touches a GPU) starts N children with HIP_VISIBLE_DEVICES=i, waits until all are warmed up, releases them together
+over their stdin pipes (the start barrier) and collects one JSON line each; under torch.distributed.run the ranks meet
+in a gloo (CPU) group for the same two barriers and the MAX / SUM of (seconds, tokens).  ``value`` = tokens decoded by
+all replicas / max over replicas of the wall time of the K steps.
 
 Besides the contract's fields the JSON line carries
   roofline      for the dominant kernel: algorithmic bytes per launch / its mean duration, measured live with HIP
                 events taken from each dispatch (profiling sink of the library), against 8 TB/s;
-  step_roofline the same for the whole token (all algorithmic bytes / wall time per token) — includes launch gaps;
-  cpu_baseline  the CPU oracle (a port of the reference's generate()+model) timed on this host's cores on a bounded
-                sample of the same workload.
+  step_roofline the same for the whole token (all algorithmic bytes / wall time per token) - includes launch gaps;
+  cpu_baseline  the CPU oracle (a port of the reference's generate()+model) timed on this host's cores: Pythia-160M fp32
+                128 -> 64 tokens (BASELINE configs[0]) and a bounded sample of this workload's decode steps.
 """
 import argparse
 import json
@@ -25,8 +29,7 @@ import sys
 import time
 from pathlib import Path
 
-# the pool's driver only supports dmabuf IPC: RCCL (the timing barrier at N > 1) fails with the legacy mode
-os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # the pool's driver only supports dmabuf IPC (kept in every child env)
 os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
 
 import torch  # noqa: E402
@@ -92,17 +95,19 @@ def kernel_bytes_per_token(cfg, mode):
 
 PMC_KERNEL_PREFIX = {"w4_gemv": "w4_gemv_kernel<1, false", "w4_gemv_dual": "w4_gemv_kernel<1, true",
                      "bf16_gemv": "bf16_gemv_kernel<1, false", "bf16_gemv_dual": "bf16_gemv_kernel<1, true",
-                     "w8_gemv": "w8_gemv_kernel", "attn_fused_decode": "attn_fused_decode_kernel"}
+                     "w8_gemv": "w8_gemv_kernel", "attn_fused_decode": "attn_fused_decode_kernel", "eng_token": "eng_token_kernel"}
 
 
 def pmc_traffic(kernel: str):
     """HBM bytes per launch of ``kernel`` from the newest committed PMC summary (profiles/*_pmc_traffic.json, written by
     tools/summarize_profiles.py from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this benchmark).
-    Counters cannot be collected inside the timed run; returns (bytes per launch or None, source file)."""
+    Counters cannot be collected inside the timed run; returns (bytes per launch or None, source file, problem or None).
+    A summary without a kernel of the expected name is STALE (the kernels changed since it was taken): that is reported as a
+    problem, printed on stderr and asserted by tests/test_bench_host.py - never papered over with an old number."""
     files = sorted((REPO / "profiles").glob("*_pmc_traffic.json"))
     prefix = PMC_KERNEL_PREFIX.get(kernel)
     if not files or prefix is None:
-        return None, None
+        return None, None, "no PMC summary for this kernel"
     entries = json.loads(files[-1].read_text())["kernels"]
     tot_b = tot_n = 0.0
     for name, v in entries.items():
@@ -110,7 +115,9 @@ def pmc_traffic(kernel: str):
             n = v.get("launches_FETCH_SIZE", 1)
             tot_b += v["hbm_bytes_per_launch_corrected"] * n
             tot_n += n
-    return (tot_b / tot_n if tot_n else None), files[-1].name
+    if not tot_n:
+        return None, files[-1].name, f"STALE: {files[-1].name} holds no kernel named {prefix}*"
+    return tot_b / tot_n, files[-1].name, None
 
 
 def rank_env():
@@ -120,38 +127,121 @@ def rank_env():
     return rank, local, world
 
 
-def max_over_ranks(seconds: float, units: int, world: int, device) -> tuple:
-    """(max elapsed over ranks, total units over ranks).  The only collective of the benchmark (timing only)."""
+def max_over_ranks(seconds: float, units: int, world: int, device=None) -> tuple:
+    """(max elapsed over ranks, total units over ranks) under an external launcher: CPU tensors over gloo (timing only)."""
     if world == 1:
         return seconds, units
     import torch.distributed as dist
 
-    t = torch.tensor([seconds], dtype=torch.float64, device=device)
-    u = torch.tensor([units], dtype=torch.int64, device=device)
+    t = torch.tensor([seconds], dtype=torch.float64)
+    u = torch.tensor([units], dtype=torch.int64)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dist.all_reduce(u, op=dist.ReduceOp.SUM)
     return float(t.item()), int(u.item())
 
 
 def barrier(world: int, device) -> None:
+    """device work done, then (under an external launcher) the gloo barrier: no RCCL, no GPU buffer leaves its process"""
+    if device is not None and device.type == "cuda":
+        torch.cuda.synchronize(device)
     if world > 1:
         import torch.distributed as dist
 
-        dist.barrier(device_ids=[device.index] if device.type == "cuda" else None)
-    if device.type == "cuda":
-        torch.cuda.synchronize(device)
+        dist.barrier()
 
 
-def cpu_baseline(cfg, mode, model, prompt_cpu, budget_s: float = 20.0):
-    """Time the CPU oracle (port of the reference path) on a bounded sample: a short prompt prefix, then single-token
-    decode steps until ~budget_s of CPU work.  Returns the cpu_baseline object."""
+# ---------------------------------------------------------------------------------------------- self-contained replicas
+def aggregate_replicas(lines):
+    """One whole-job result from the replicas' JSON lines: tokens of all replicas / the slowest replica's wall time."""
+    elapsed = max(r["elapsed_s"] for r in lines)
+    units = sum(r["steps"] for r in lines)
+    out = dict(lines[0])
+    out.update(value=units / elapsed, n_gpus=len(lines), ms_per_step=elapsed / lines[0]["steps"] * 1e3,
+               replicas=[{"device": r["device"], "value": r["value"], "ms_per_step": r["ms_per_step"],
+                          "roofline_frac": (r.get("roofline") or {}).get("frac"),
+                          "step_roofline_frac": (r.get("step_roofline") or {}).get("frac")} for r in lines])
+    out["config"] = dict(out["config"], replicas=len(lines), parallelism=f"replicas x{len(lines)} (no collective, no RCCL)")
+    for k in ("elapsed_s", "device"):
+        out.pop(k, None)
+    return out
+
+
+def spawn_replicas(args, argv, child_cmd=None):
+    """Parent of ``--gpus N`` without an external launcher.  Never initialises a GPU.  Children: fresh interpreters with
+    HIP_VISIBLE_DEVICES pinned (``--devices 0,0`` overrides, e.g. two replicas on a one-GPU box), that print READY when
+    warmed up, block on stdin until released together, and print their JSON line."""
+    import subprocess
+
+    n = args.gpus
+    devs = [d.strip() for d in args.devices.split(",")] if args.devices else [str(i) for i in range(n)]
+    if len(devs) != n:
+        raise SystemExit(f"--devices lists {len(devs)} devices for --gpus {n}")
+    procs = []
+    for i in range(n):
+        env = dict(os.environ, HIP_VISIBLE_DEVICES=devs[i], PARROT_BENCH_REPLICA=str(i), PARROT_BENCH_WORLD=str(n),
+                   HSA_ENABLE_IPC_MODE_LEGACY="0")
+        for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
+            env.pop(k, None)
+        cmd = (child_cmd or [sys.executable, str(Path(__file__).resolve())]) + argv
+        procs.append(subprocess.Popen(cmd, env=env, stdin=subprocess.PIPE, stdout=subprocess.PIPE, text=True, bufsize=1))
+
+    def read_until(p, word):
+        for line in p.stdout:
+            if line.strip() == word:
+                return True
+        return False
+
+    try:
+        for i, p in enumerate(procs):
+            if not read_until(p, "READY"):
+                raise SystemExit(f"replica {i} ended before it was ready (exit code {p.wait()})")
+        for p in procs:  # the start barrier: everybody is warmed up and synchronised; release them together
+            p.stdin.write("GO\n")
+            p.stdin.flush()
+        lines = []
+        for i, p in enumerate(procs):
+            got = [json.loads(l) for l in p.stdout if l.startswith("{")]
+            if p.wait() != 0 or not got:
+                raise SystemExit(f"replica {i} failed (exit code {p.returncode})")
+            lines.append(got[-1])
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    return aggregate_replicas(lines)
+
+
+def cpu_pythia_leg():
+    """BASELINE.json configs[0] / SURVEY §8(d): Pythia-160M fp32, greedy 128 -> 64 tokens through the oracle's generate()
+    (the reference's loop, restated) on the host cores.  tokens/s as the reference defines it (new tokens / wall, prefill
+    included, generate/base.py:239-255)."""
+    from lit_parrot_amd.config import Config
+    from lit_parrot_amd.synth import synthetic_prompt, synthetic_state_dict
     from oracle import model as om
 
+    cfg = Config.from_name("pythia-160m")
+    oracle = om.OracleGPT(cfg, synthetic_state_dict(cfg, 1234))
+    prompt = synthetic_prompt(cfg, 128, 1234)
+    t0 = time.perf_counter()
+    y = om.generate(oracle, prompt, 192, 192, greedy_ties_lowest=True)
+    el = time.perf_counter() - t0
+    return {"value": (y.numel() - 128) / el, "unit": "tokens/s", "seconds": el, "sample": "pythia-160m fp32, 128-token prompt + 64 greedy tokens, prefill included"}
+
+
+def cpu_baseline(cfg, mode, model, prompt_cpu, budget_s: float = 20.0, min_tokens: int = 1):
+    """Time the CPU oracle (port of the reference path) on the host cores: the Pythia-160M leg always, then a bounded sample
+    of THIS workload - a short prompt prefix, then single-token decode steps until ~budget_s of CPU work, at least
+    ``min_tokens`` of them (``--cpu-full`` asks for the 8 that SURVEY §8(d) names: ~33 s each on Llama-2-7B, because the
+    reference's CPU path dequantises every matrix on every call, quantize/gptq.py:263 - keeping the dequantised matrices
+    across steps would no longer be the reference's path).  Returns the cpu_baseline object."""
+    from oracle import model as om
+
+    out = {"value": None, "unit": "tokens/s", "cores": torch.get_num_threads(), "kind": "port", "pythia_160m_fp32": cpu_pythia_leg()}
     tile_cols = 128 if (mode or "").endswith("g128") else -1
     sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
     if mode == "bnb.int8" or (mode or "").startswith(("bnb.nf4", "bnb.fp4")):
-        return {"value": None, "unit": "tokens/s", "cores": torch.get_num_threads(), "kind": "port",
-                "sample": "skipped: the state dict of this mode holds only quantised weights"}
+        out["sample"] = "workload leg skipped: the state dict of this mode holds only quantised weights"
+        return out
     oracle = om.OracleGPT(cfg, sd, "gptq" if mode and mode.startswith("gptq") else "dense", tile_cols=tile_cols)
     T0 = 4
     S = T0 + 64
@@ -165,10 +255,10 @@ def cpu_baseline(cfg, mode, model, prompt_cpu, budget_s: float = 20.0):
             logits = oracle(tok, S, pos)
             n += 1
             el = time.perf_counter() - t0
-            if el > budget_s or n >= 60:
+            if (el > budget_s and n >= min_tokens) or n >= 60:
                 break
-    return {"value": n / el, "unit": "tokens/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"{n} single-token decode steps after a {T0}-token prompt, same weights, oracle/model.py on the host CPU"}
+    out.update(value=n / el, sample=f"{n} single-token decode steps after a {T0}-token prompt ({el:.1f} s), same weights, oracle/model.py on the host CPU")
+    return out
 
 
 def main() -> None:
@@ -179,12 +269,22 @@ def main() -> None:
     ap.add_argument("--workload", default="llama2-7b-int4", choices=sorted(WORKLOADS))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=20.0)
+    ap.add_argument("--cpu-full", action="store_true", help="cpu_baseline: at least 8 decode tokens of the workload (minutes on Llama-2-7B)")
+    ap.add_argument("--devices", default="", help="comma list of HIP_VISIBLE_DEVICES values for the replicas spawned by --gpus N (default 0..N-1)")
     ap.add_argument("--engine", type=int, default=-1, help="1 / 0: force the one-launch stream engine on / off (default: the library's choice)")
     args = ap.parse_args()
 
     rank, local, world = rank_env()
-    if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    replica = os.environ.get("PARROT_BENCH_REPLICA")
+    if replica is None and world == 1 and args.gpus > 1:
+        # no external launcher: this process becomes the parent of N fresh replicas and never touches a GPU
+        argv = [a for a in sys.argv[1:]]
+        print(json.dumps(spawn_replicas(args, argv)), flush=True)
+        return
+    if replica is not None:  # a child of spawn_replicas: one replica on the one device it can see
+        rank, local, world = int(replica), 0, 1
+    elif world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}, or without a launcher")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device: the decode path has no CPU fallback")
     device = torch.device("cuda", local)
@@ -192,7 +292,7 @@ def main() -> None:
     if world > 1:
         import torch.distributed as dist
 
-        dist.init_process_group("nccl", device_id=device)
+        dist.init_process_group("gloo")  # timing barriers and two scalar reductions on CPU tensors: no RCCL
 
     import lit_parrot_amd as L
     from lit_parrot_amd import _hip
@@ -229,6 +329,10 @@ def main() -> None:
         for _ in range(args.warmup):
             sess.step()
         barrier(world, device)
+        if replica is not None:  # spawned replica: tell the parent, then wait to be released together with the others
+            print("READY", flush=True)
+            if sys.stdin.readline().strip() != "GO":
+                raise SystemExit("replica: released without GO")
         t0 = time.perf_counter()
         for _ in range(args.steps):
             sess.step()
@@ -258,9 +362,11 @@ def main() -> None:
         bytes_per_launch = kb[dom][0] / kb[dom][1]
         avg_s = stats[dom][0] / stats[dom][1] * 1e-3
         achieved = bytes_per_launch / avg_s / 1e9
-        traffic, traffic_src = pmc_traffic(dom) if args.workload == "llama2-7b-int4" else (None, None)
+        traffic, traffic_src, traffic_problem = pmc_traffic(dom) if args.workload == "llama2-7b-int4" else (None, None, None)
+        if traffic_problem and args.workload == "llama2-7b-int4":
+            print(f"bench.py: roofline.traffic unavailable - {traffic_problem}", file=sys.stderr, flush=True)
         roofline = {"kernel": dom, "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src,
+                    "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src, "traffic_problem": traffic_problem,
                     "bytes_per_launch": bytes_per_launch,
                     "avg_launch_us": avg_s * 1e6, "launches_per_token": kb[dom][1]}
     step_gbs = (w_bytes + kv_bytes) / (ms_per_step * 1e-3) / 1e9
@@ -280,7 +386,7 @@ def main() -> None:
         "dtype": dtype_label,
         "data": "synthetic",
         "config": {"workload": f"{cfg_name} {mode or 'bf16'} single-stream decode, {T}-token prompt, random-init weights",
-                   "prompt_tokens": T, "replicas": world, "parallelism": f"replicas x{world} (no collective)",
+                   "prompt_tokens": T, "replicas": world, "parallelism": f"replicas x{world} (no collective, no RCCL)",
                    "graph": "hipGraph replay per token"},
         "roofline": roofline,
         "step_roofline": {"bound": "hbm", "achieved": step_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -296,17 +402,24 @@ def main() -> None:
         "prefill_roofline": {"bound": "mfma", "achieved": prefill_flops / t_pre / 1e12, "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
                              "frac": prefill_flops / t_pre / 1e12 / MFMA_BF16_PEAK_TFLOPS, "linear_flops": prefill_flops},
         "build_s": t_build,
+        "engine": sess.eng is not None,
     }
+    if replica is not None:  # the parent aggregates: it needs this replica's own clock
+        result.update(elapsed_s=elapsed, device=os.environ.get("HIP_VISIBLE_DEVICES", "?"), cpu_baseline=None)
+        if rank == 0 and not args.no_cpu_baseline and int(os.environ.get("PARROT_BENCH_WORLD", "1")) == 1:
+            result["cpu_baseline"] = cpu_baseline(cfg, mode, model, prompt, args.cpu_budget, 8 if args.cpu_full else 1)
+        print(json.dumps(result), flush=True)
+        return
     if rank == 0:
         if args.no_cpu_baseline or world > 1:
             result["cpu_baseline"] = None
         else:
-            result["cpu_baseline"] = cpu_baseline(cfg, mode, model, prompt, args.cpu_budget)
+            result["cpu_baseline"] = cpu_baseline(cfg, mode, model, prompt, args.cpu_budget, 8 if args.cpu_full else 1)
         print(json.dumps(result), flush=True)
     if world > 1:
         import torch.distributed as dist
 
-        dist.barrier(device_ids=[device.index])
+        dist.barrier()
         dist.destroy_process_group()
 
 

@@ -154,6 +154,11 @@ def generate(
     if not isinstance(model, GPT):
         raise ParrotHipError("generate() drives lit_parrot_amd.GPT models")
     assert max_seq_length <= model.config.block_size
+    if max_returned_tokens > model.config.block_size:
+        # positions index the RoPE tables (block_size rows); the reference fails at rope.index_select in this case
+        # (lit_gpt/model.py:88) - here the kernels would read past the tables on the device
+        raise ParrotHipError(f"max_returned_tokens={max_returned_tokens} exceeds block_size={model.config.block_size}: "
+                             "positions past the RoPE tables")
     assert max_seq_length >= T, f"Cannot forward sequence of length {T}, max seq length is only {max_seq_length}"
     dtype = idx.dtype
     greedy = top_k == 1 and temperature > 0

@@ -229,6 +229,8 @@ class GPT(nn.Module):
             S = self.kv_caches[0][0].size(2)
             if input_pos.numel() != T:
                 raise ParrotHipError("input_pos must hold one position per token")
+            if not input_pos.is_cuda and int(input_pos[-1]) >= block_size:  # a host value: check it (the reference raises in index_select)
+                raise IndexError(f"input_pos {int(input_pos[-1])} is past the RoPE tables (block_size {block_size})")
             pos = input_pos[:1].to(torch.int32)
         else:
             S = T

@@ -42,6 +42,16 @@ def test_argument_validation_needs_no_gpu(hip_lib):
     assert hip_lib.parrot_w4_packed_bytes(8, 100, 32) == -3  # K not a multiple of 32
     assert "multiple of 32" in _hip.last_error()
     assert hip_lib.parrot_kernel_name(0) == b"w4_gemv" and hip_lib.parrot_kernel_name(999) == b"?"
+    # stream engine: layout sizes and shape limits are host arithmetic
+    assert hip_lib.parrot_e4_bytes(4096, 4096, 0) == 512 * 17 * 1024  # 512 blocks of 8 rows: 16 weight pieces + 1 metadata piece
+    assert hip_lib.parrot_e4_bytes(11008, 4096, 1) == (11008 // 4) * 17 * 1024  # SwiGLU pair: 4 + 4 rows per block
+    assert hip_lib.parrot_e4_bytes(4096, 11008, 0) == 512 * (44 + 3) * 1024  # 11 quads in 3 slots
+    assert hip_lib.parrot_e4_bytes(4096, 4100, 0) == -3 and hip_lib.parrot_e4_bytes(4095, 4096, 0) == -3
+    assert hip_lib.parrot_e4_bytes(64, 16384, 0) == -3 and "stream engine" in _hip.last_error()
+    assert hip_lib.parrot_eng_lds_bytes(4096, 0, 0, 0) == 32 * 272
+    assert hip_lib.parrot_eng_lds_bytes(11008, 128, 1, 8) == 88 * 272
+    assert hip_lib.parrot_eng_step(None, None) == -1
+    assert hip_lib.parrot_w8_quantize_rows(None, 0, 1, 1, None, None, None) == -1
 
 
 @pytest.mark.parametrize("N,K,group,expect", [
@@ -68,6 +78,9 @@ def test_no_cpu_fallback():
         lin(torch.zeros(1, 64, dtype=torch.bfloat16))
     with pytest.raises(L.ParrotHipError):
         L.generate(model, torch.zeros(4, dtype=torch.int64), 8, 8, top_k=1)
+    # positions past the RoPE tables are refused on the host (the reference raises in index_select, lit_gpt/model.py:88)
+    with pytest.raises(L.ParrotHipError, match="block_size"):
+        L.generate(model, torch.zeros(4, dtype=torch.int64), cfg.block_size + 1, cfg.block_size, top_k=1)
     # the product never imports the oracle
     for f in (REPO / "lit-parrot_amd").rglob("*.py"):
         assert "oracle" not in f.read_text().replace("oracle/", "").replace("the oracle", ""), f

@@ -1,5 +1,8 @@
-"""The N > 1 path of bench.py: independent replicas that only meet to agree on (max seconds, total tokens).
-Exercised with world_size 2 over gloo on the CPU (the data path itself has no collective)."""
+"""The N > 1 paths of bench.py: independent replicas that only meet to agree on (max seconds, total tokens).
+Under an external launcher: world_size 2 over gloo on the CPU.  Without one: the parent spawns its replicas, pins a device
+to each, releases them together and aggregates their lines - exercised here with a stub child (no GPU)."""
+import json
+import types
 import os
 import sys
 from pathlib import Path
@@ -57,3 +60,54 @@ def test_byte_accounting_matches_the_survey():
     kb = bench.kernel_bytes_per_token(l7, "gptq.int4-g128")
     assert kb["w4_gemv"][1] == 97 and kb["w4_gemv_dual"][1] == 32
     assert kb["w4_gemv"][0] + kb["w4_gemv_dual"][0] == w
+
+
+STUB = '''
+import json, os, sys, time
+i = int(os.environ["PARROT_BENCH_REPLICA"])
+assert os.environ["PARROT_BENCH_WORLD"] == "2" and "WORLD_SIZE" not in os.environ and os.environ["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+print("replica", i, "warming up", flush=True)
+print("READY", flush=True)
+assert sys.stdin.readline().strip() == "GO"
+steps = int(sys.argv[sys.argv.index("--steps") + 1])
+elapsed = 1.0 + i  # replica i "decodes" its steps in 1 + i seconds
+print(json.dumps({"metric": "m", "value": steps / elapsed, "steps": steps, "elapsed_s": elapsed, "ms_per_step": elapsed / steps * 1e3,
+                  "device": os.environ["HIP_VISIBLE_DEVICES"], "roofline": {"frac": 0.5 - 0.1 * i}, "step_roofline": {"frac": 0.4},
+                  "config": {"workload": "stub", "replicas": 1}}), flush=True)
+'''
+
+
+def test_self_spawned_replicas_with_a_stub_child(tmp_path):
+    """python bench.py --gpus 2 without a launcher: device pinning, start barrier over the pipes, aggregation."""
+    sys.path.insert(0, str(REPO))
+    import bench
+
+    stub = tmp_path / "stub.py"
+    stub.write_text(STUB)
+    for devices, expect in (("", ["0", "1"]), ("0,0", ["0", "0"])):
+        args = types.SimpleNamespace(gpus=2, devices=devices)
+        out = bench.spawn_replicas(args, ["--gpus", "2", "--steps", "100"], child_cmd=[sys.executable, str(stub)])
+        assert out["n_gpus"] == 2 and out["value"] == 200 / 2.0 and abs(out["ms_per_step"] - 20.0) < 1e-9
+        assert [r["device"] for r in out["replicas"]] == expect
+        assert [r["roofline_frac"] for r in out["replicas"]] == [0.5, 0.4]
+        assert out["config"]["replicas"] == 2 and "no RCCL" in out["config"]["parallelism"]
+        assert "elapsed_s" not in out
+    with __import__("pytest").raises(SystemExit):
+        bench.spawn_replicas(types.SimpleNamespace(gpus=2, devices="0"), [], child_cmd=[sys.executable, str(stub)])
+    # a replica that dies before it is ready fails the job
+    bad = tmp_path / "bad.py"
+    bad.write_text("import sys; sys.exit(3)")
+    with __import__("pytest").raises(SystemExit):
+        bench.spawn_replicas(types.SimpleNamespace(gpus=2, devices=""), ["--steps", "1"], child_cmd=[sys.executable, str(bad)])
+
+
+def test_committed_pmc_summary_names_the_running_kernels():
+    """roofline.traffic comes from the newest profiles/*_pmc_traffic.json: it must have been taken with kernels of the names
+    the benchmark runs today (a renamed or retired kernel makes the summary stale - re-measure, do not reuse the number)."""
+    sys.path.insert(0, str(REPO))
+    import bench
+
+    for kernel in ("w4_gemv", "w4_gemv_dual"):
+        traffic, src, problem = bench.pmc_traffic(kernel)
+        assert problem is None and traffic and src, (kernel, problem)
+    assert bench.pmc_traffic("no_such_kernel")[2] is not None
