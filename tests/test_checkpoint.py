@@ -136,9 +136,9 @@ def test_stream_load_quantises_on_the_way_in(hip_lib, tmp_path, mode):
             assert torch.equal(mod.quant_weight, pack_nibbles(q)) and torch.equal(mod.scales, s) and torch.equal(mod.zeros, z), name
             n_checked += 1
         elif isinstance(mod, InferenceLinear8bitLt):
-            from oracle.int8 import quantize_weight_rows  # the checker (CPU): row absmax int8 of the bf16 weights
+            from oracle.int8 import quantize_weight_rows  # the checker (CPU): row absmax int8 of `weight.half()` (quantize/bnb.py:54)
 
-            CB, SCB = quantize_weight_rows(sd[name + ".weight"].to(torch.bfloat16))
+            CB, SCB = quantize_weight_rows(sd[name + ".weight"])  # the checkpoint's own precision, not a bf16 detour
             assert mod.weight.dtype == torch.int8
             assert torch.equal(mod.weight.SCB.cpu(), SCB), name
             assert torch.equal(mod.weight.data.cpu(), CB), name
