@@ -210,3 +210,28 @@ def test_engine_refuses_unsupported_models():
     assert "group size" in StreamEngine.supported(m2)
     with pytest.raises(_hip.ParrotHipError):
         StreamEngine(m2, torch.zeros(8, dtype=torch.int64, device=DEV), torch.zeros(1, dtype=torch.int32, device=DEV), [], 8, True)
+
+
+@torch.no_grad()
+def test_engine_at_llama2_7b_width_and_a_long_window():
+    """The engine on the real launch shapes (4096 / 12288 / 11008 / 32000 rows and columns: K = 11008 spans three ring slots
+    per block, 8 key splits per head), two layers deep, against the multi-launch step on the same forced tokens - once behind a
+    short prompt and once behind a 1100-token prompt in a 1200-slot window, where a CU's keys span several K/V ring slots."""
+    from lit_parrot_amd.config import name_to_config
+    from lit_parrot_amd.synth import build_synthetic_model
+
+    cfg = Config(**{**name_to_config["Llama-2-7b-hf"], "n_layer": 2})
+    model = build_synthetic_model(cfg, "gptq.int4-g128", seed=1234, device=DEV)
+    assert StreamEngine.supported(model) is None
+    for T, S, n in ((40, 96, 16), (1100, 1200, 12)):
+        prompt = synthetic_prompt(cfg, T, 7)
+        tok_a, log_a = run_session(model, prompt, n, engine=False, S=S)
+        tok_b, log_b = run_session(model, prompt, n, engine=True, S=S, follow=tok_a.to(DEV))
+        d = (log_a - log_b).abs()
+        scale = max(1.0, float(log_a.abs().max()))
+        assert float(d.max()) <= 2 ** -5 * scale and float(d.mean()) <= 2e-3 * scale, (T, float(d.max()), float(d.mean()))
+        tok_c, log_c = run_session(model, prompt, n, engine=True, S=S)
+        tok_d, log_d = run_session(model, prompt, n, engine=True, S=S, use_graph=False)
+        assert torch.equal(tok_c, tok_d) and torch.equal(log_c, log_d)
+    del model
+    torch.cuda.empty_cache()

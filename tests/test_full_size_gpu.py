@@ -84,10 +84,12 @@ def test_llama2_7b_int4_prefill_equals_decode_and_replay_is_deterministic(llama7
 
 
 @torch.no_grad()
-@pytest.mark.parametrize("mode", ["gptq.int4-g128", "bnb.nf4", None])
+@pytest.mark.parametrize("mode", ["gptq.int4-g128", "bnb.nf4", None, "bnb.int8"])
 def test_llama2_7b_width_two_layers_prefill_equals_decode(mode):
     """Full-width Linears (4096 / 11008 / 32000, every launch shape of the 7B step and prompt), two layers deep: the prompt path and
-    the decode path agree within the int4 bound of north_star plus one bf16 ulp of the logits."""
+    the decode path agree within the int4 bound of north_star plus one bf16 ulp of the logits.  LLM.int8 (BASELINE configs[2]): the
+    prompt takes its outlier columns over all its rows and a decode step over its one row (the published rule), and
+    every Linear re-quantises its input to int8 - the two paths are two quantisations of the same network: bound 5e-2 / 8e-3."""
     from lit_parrot_amd.config import name_to_config
 
     cfg = Config(**{**name_to_config["Llama-2-7b-hf"], "n_layer": 2})
@@ -99,9 +101,89 @@ def test_llama2_7b_width_two_layers_prefill_equals_decode(mode):
     model.reset_cache()
     ld = _decode_path_logits(model, prompt, S).float().view(-1)
     scale = max(1.0, float(ld.abs().max()))
+    tol_max, tol_mean, tol_top = ((5e-2, 8e-3, 5e-2) if mode == "bnb.int8" else (1e-2 + 2 ** -7, 3e-3, 2 ** -6))
+    assert float((lp - ld).abs().max()) <= tol_max * scale, float((lp - ld).abs().max())
+    assert float((lp - ld).abs().mean()) <= tol_mean * scale, float((lp - ld).abs().mean())
+    assert float(ld[lp.argmax()]) >= float(ld.max()) - tol_top * scale
+    del model, sess
+    torch.cuda.empty_cache()
+
+
+@torch.no_grad()
+def test_llama2_7b_int8_fused_swiglu_rows_against_the_oracle():
+    """BASELINE configs[2] at full width: the decode launch of the LLM.int8 MLP - activation quantiser fused with the
+    [fc_1; fc_2] int8 GEMV (22016 x 4096) and the SwiGLU epilogue - against oracle/int8.py on sampled rows, with outliers."""
+    from lit_parrot_amd._hip import EPI_SWIGLU
+    from lit_parrot_amd.quantize.bnb import InferenceLinear8bitLt
+    from oracle import int8 as o8
+
+    g = torch.Generator().manual_seed(11)
+    K, N = 4096, 11008
+    fc1, fc2 = InferenceLinear8bitLt(K, N, bias=False), InferenceLinear8bitLt(K, N, bias=False)
+    W1, W2 = (torch.randn(N, K, generator=g) * 0.02).half(), (torch.randn(N, K, generator=g) * 0.02).half()  # an fp16 checkpoint
+    fc1.load_state_dict({"weight": W1})
+    fc2.load_state_dict({"weight": W2})
+    x = torch.randn(1, K, generator=g).to(BF)
+    x[0, 5], x[0, 4000], x[0, 2049] = 8.0, -6.5, 30.0
+    h = torch.empty((1, N), dtype=BF, device=DEV)
+    fc1.hip_linear(x.to(DEV), h, epilogue=EPI_SWIGLU, partner=fc2)
+    rows = torch.randint(0, N, (96,), generator=g)
+    cb1, scb1 = o8.quantize_weight_rows(W1[rows])
+    cb2, scb2 = o8.quantize_weight_rows(W2[rows])
+    assert torch.equal(fc1.weight.data[rows.to(DEV)].cpu(), cb1) and torch.equal(fc2.weight.SCB[rows.to(DEV)].cpu(), scb2)
+    a, b = o8.linear(x, cb1, scb1, None, 6.0).float(), o8.linear(x, cb2, scb2, None, 6.0).float()
+    want = rbf(torch.nn.functional.silu(a)) * b  # bf16(silu(bf16 acc1)) * bf16 acc2, rounded once more by the kernel
+    assert_bf16_close(h.cpu().view(-1)[rows], want.view(-1), ulps=1, atol=1e-3, what="int8 SwiGLU rows")
+
+
+@torch.no_grad()
+def test_falcon_40b_width_two_layers_prefill_equals_decode_and_mlp_rows():
+    """BASELINE configs[4] at full width, two layers deep: n_embd 8192, fused QKV 9216 rows (8 groups of 16 query heads, head size
+    64), MLP 32768 (K = 32768 -> 16 slabs in the down-projection), vocabulary 65024, LayerNorm, parallel residual (the MLP
+    up-projection on the side stream).  Prompt path == decode path within the int4 bound; sampled rows of the GELU up-projection and
+    of the 32768-column down-projection against float64 arithmetic on the dequantised rows."""
+    from lit_parrot_amd._hip import EPI_GELU
+    from lit_parrot_amd.config import name_to_config
+
+    cfg = Config(**{**name_to_config["falcon-40b"], "n_layer": 2})
+    model = build_synthetic_model(cfg, "gptq.int4-g128", seed=1234, device=DEV)
+    T, S = 130, 160
+    prompt = synthetic_prompt(cfg, T, seed=4).to(DEV)
+    sess = gb.DecodeSession(model, S, S, greedy=False, use_graph=False)
+    lp = sess.prefill(prompt).float().view(-1).clone()
+    model.reset_cache()
+    ld = _decode_path_logits(model, prompt, S).float().view(-1)
+    scale = max(1.0, float(ld.abs().max()))
     assert float((lp - ld).abs().max()) <= (1e-2 + 2 ** -7) * scale, float((lp - ld).abs().max())
     assert float((lp - ld).abs().mean()) <= 3e-3 * scale
     assert float(ld[lp.argmax()]) >= float(ld.max()) - 2 ** -6 * scale
+    # graph replay == eager launches on the parallel-branch step
+    runs = []
+    for use_graph in (True, False):
+        model.reset_cache()
+        s2 = gb.DecodeSession(model, S, S, greedy=True, use_graph=use_graph)
+        ops.argmax_advance(s2.prefill(prompt), s2.tokens, s2.pos)
+        s2.capture()
+        for _ in range(12):
+            s2.step()
+        runs.append(s2.tokens[: T + 13].clone())
+    assert torch.equal(runs[0], runs[1])
+    g = torch.Generator().manual_seed(6)
+    mlp = model.transformer.h[1].mlp
+    x = torch.randn(1, cfg.n_embd, generator=g).to(BF)
+    h = torch.empty((1, cfg.intermediate_size), dtype=BF, device=DEV)
+    mlp.fc.hip_linear(x.to(DEV), h, epilogue=EPI_GELU)
+    rows = torch.randint(0, cfg.intermediate_size, (64,), generator=g)
+    W = mlp.fc.get_weight(torch.float32)[rows.to(DEV)].double().cpu()
+    v = rbf(x.double() @ W.t())
+    want = 0.5 * v * (1.0 + torch.erf(v / 2.0 ** 0.5))
+    assert_bf16_close(h.cpu().view(-1)[rows], want.view(-1), ulps=1, atol=2e-3, what="falcon-40b GELU rows")
+    hx = (torch.randn(1, cfg.intermediate_size, generator=g) * 0.5).to(BF)
+    out = torch.empty((1, cfg.n_embd), dtype=BF, device=DEV)
+    mlp.proj.hip_linear(hx.to(DEV), out)
+    rows = torch.randint(0, cfg.n_embd, (64,), generator=g)
+    W = mlp.proj.get_weight(torch.float32)[rows.to(DEV)].double().cpu()
+    assert_bf16_close(out.cpu().view(-1)[rows], rbf(hx.double() @ W.t()).view(-1), ulps=1, atol=4e-3, what="falcon-40b down-projection rows (K = 32768)")
     del model, sess
     torch.cuda.empty_cache()
 
