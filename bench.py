@@ -49,6 +49,10 @@ WORKLOADS = {
     "stablelm-3b-bf16": ("stablelm-base-alpha-3b", None, 512, "bf16"),
     "falcon-40b-int4": ("falcon-40b", "gptq.int4-g128", 128, "u4 weights, bf16 activations, fp32 accumulate"),
     "pythia-160m-bf16": ("pythia-160m", None, 128, "bf16"),
+    # the one model the reference publishes tokens/s for (tutorials/quantize.md:16-128, on its authors' GPU): bf16 / bnb.int8 / gptq.int4
+    "falcon-7b-bf16": ("falcon-7b", None, 128, "bf16"),
+    "falcon-7b-int8": ("falcon-7b", "bnb.int8", 128, "int8"),
+    "falcon-7b-int4": ("falcon-7b", "gptq.int4", 128, "u4 weights (per-channel scales, the reference's gptq.int4), bf16 activations, fp32 accumulate"),
     "tiny-llama-int4": ("tiny-llama", "gptq.int4-g128", 16, "u4 weights, bf16 activations, fp32 accumulate"),
 }
 
@@ -271,6 +275,7 @@ def main() -> None:
     ap.add_argument("--cpu-budget", type=float, default=20.0)
     ap.add_argument("--cpu-full", action="store_true", help="cpu_baseline: at least 8 decode tokens of the workload (minutes on Llama-2-7B)")
     ap.add_argument("--devices", default="", help="comma list of HIP_VISIBLE_DEVICES values for the replicas spawned by --gpus N (default 0..N-1)")
+    ap.add_argument("--attn-split-keys", type=int, default=0, help="A/B: window slots per sequence split of the decode attention (default: the library's)")
     ap.add_argument("--engine", type=int, default=-1, help="1 / 0: force the one-launch stream engine on / off (default: the library's choice)")
     args = ap.parse_args()
 
@@ -304,6 +309,10 @@ def main() -> None:
         from lit_parrot_amd.generate import base as _gb
 
         _gb.ENGINE_DEFAULT = bool(args.engine)
+    if args.attn_split_keys > 0:
+        from lit_parrot_amd import ops as _ops
+
+        _ops.ATTN_SPLIT_KEYS = args.attn_split_keys
     cfg_name, mode, T, dtype_label = WORKLOADS[args.workload]
     cfg = Config.from_name(cfg_name)
     total = T + args.warmup + args.steps + 1

@@ -136,6 +136,9 @@ _TABLE = [
     dict(_falcon("tiny-falcon-gqa", 2, 8, 256, 2), org="test", block_size=128, vocab_size=512, padded_vocab_size=512),
     dict(_falcon("tiny-falcon-mqa", 2, 4, 128, 1, shared_attention_norm=True), org="test", block_size=128,
          vocab_size=512, padded_vocab_size=512),
+    # Falcon-7B's odd shapes in small: width not a multiple of 128 (4544 = 71 x 64), an odd number of query heads on one K/V head
+    dict(_falcon("tiny-falcon-7b", 2, 7, 448, 1, shared_attention_norm=True), org="test", block_size=128,
+         vocab_size=512, padded_vocab_size=512),
 ]
 
 name_to_config: Dict[str, Dict[str, Any]] = {c["name"]: c for c in _TABLE}

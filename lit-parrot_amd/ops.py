@@ -275,6 +275,10 @@ def rope_kvappend(qkv: torch.Tensor, cos: torch.Tensor, sin: torch.Tensor, n_ele
                                                ptr(v_cache), stream()), "parrot_qkv_rope_kvappend")
 
 
+FUSED_ATTN_MAX_Q_PER_KV = 16  # query heads per group the fused single-row kernel is built for
+ATTN_SPLIT_KEYS = 1024  # window slots per sequence split of the decode attention (bench.py --attn-split-keys: A/B)
+
+
 def attn_nsplit(n_groups: int, S: int, q_per_kv: int = 1, M: int = 1) -> int:
     """Sequence splits of the decode-attention kernels: one workgroup walks up to ~1k keys by itself, so windows up to
     1024 take no split at all (no partials / ticket / second pass) and longer ones ceil(S / 1024) splits.  The same rule
@@ -282,7 +286,12 @@ def attn_nsplit(n_groups: int, S: int, q_per_kv: int = 1, M: int = 1) -> int:
     mostly empty workgroups per layer and was bound by workgroup dispatch (315 us per layer; 60 us without the split)."""
     chunks = (q_per_kv + 3) // 4 if q_per_kv > 2 else 1
     cap = max(1, 1024 // (n_groups * chunks))
-    return max(1, min(-(-S // 1024), cap, 64))
+    n = max(1, min(-(-S // ATTN_SPLIT_KEYS), cap, 64))
+    if M == 1 and q_per_kv > FUSED_ATTN_MAX_Q_PER_KV:
+        # a single row of an MQA model with many query heads (Falcon-7B: 71 on one K/V head) takes the unfused kernels with one
+        # workgroup per (group, 4 heads, split): 18 workgroups on 256 CUs took 108 us per layer; aim at ~190, >= 64 keys per split
+        n = max(n, min(-(-192 // (n_groups * chunks)), max(1, S // 64), cap, 64))
+    return n
 
 
 def attn_workspace(M: int, n_head: int, hs: int, nsplit: int, device) -> torch.Tensor:
@@ -332,7 +341,6 @@ def attn_fused_decode(qkv: torch.Tensor, cos: torch.Tensor, sin: torch.Tensor, n
     return y
 
 
-FUSED_ATTN_MAX_Q_PER_KV = 16
 
 # ------------------------------------------------------------------------------------------------ step glue
 def embedding(wte: torch.Tensor, tokens: torch.Tensor, pos: Optional[torch.Tensor], M: int, out: torch.Tensor) -> torch.Tensor:
