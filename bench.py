@@ -112,16 +112,19 @@ def pmc_traffic(kernel: str):
     prefix = PMC_KERNEL_PREFIX.get(kernel)
     if not files or prefix is None:
         return None, None, "no PMC summary for this kernel"
-    entries = json.loads(files[-1].read_text())["kernels"]
-    tot_b = tot_n = 0.0
-    for name, v in entries.items():
-        if name.startswith(prefix) and "hbm_bytes_per_launch_corrected" in v:
-            n = v.get("launches_FETCH_SIZE", 1)
-            tot_b += v["hbm_bytes_per_launch_corrected"] * n
-            tot_n += n
-    if not tot_n:
-        return None, files[-1].name, f"STALE: {files[-1].name} holds no kernel named {prefix}*"
-    return tot_b / tot_n, files[-1].name, None
+    newest = files[-1].name.split("_")[0]  # the round tag: only summaries of the newest measurement pass count
+    files = [f for f in files if f.name.split("_")[0] == newest]
+    for f in reversed(files):
+        entries = json.loads(f.read_text())["kernels"]
+        tot_b = tot_n = 0.0
+        for name, v in entries.items():
+            if name.startswith(prefix) and "hbm_bytes_per_launch_corrected" in v:
+                n = v.get("launches_FETCH_SIZE", 1)
+                tot_b += v["hbm_bytes_per_launch_corrected"] * n
+                tot_n += n
+        if tot_n:
+            return tot_b / tot_n, f.name, None
+    return None, files[-1].name, f"STALE: the {newest} PMC summaries hold no kernel named {prefix}*"
 
 
 def rank_env():
