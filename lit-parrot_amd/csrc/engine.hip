@@ -35,10 +35,20 @@ namespace parrot {
 #ifndef ENG_MAXFLY_V
 #define ENG_MAXFLY_V 3
 #endif
+#ifndef ENG_KEYS_PER_SPLIT_V
+#define ENG_KEYS_PER_SPLIT_V 32
+#endif
+#ifndef ENG_POLL_SLEEP
+#define ENG_POLL_SLEEP 2
+#endif
+#ifndef ENG_GATE_DEEP
+#define ENG_GATE_DEEP 0
+#endif
 #ifndef ENG_ATTN_GATE
 #define ENG_ATTN_GATE 0
 #endif
 constexpr int ENG_WGS = PARROT_ENG_WGS;
+constexpr int ENG_KEYS_PER_SPLIT = ENG_KEYS_PER_SPLIT_V;  // keys of a head that one CU attends over before a second CU joins
 constexpr int ENG_NC = 15;                // consumer waves
 constexpr int ENG_THREADS = (ENG_NC + 1) * 64;
 constexpr int ENG_NSLOT = 7;              // ring slots
@@ -234,17 +244,23 @@ __device__ __forceinline__ void eng_block_range(int nblocks, int cu, int& b0, in
 // key range of CU c in an attention op: group g, split s; keys [kb, ke) of the n_valid admitted slots
 struct EngKeys {
     bool part;  // this CU takes part in the attention op
-    int g, s, kb, ke, nunits;
+    int g, s, ns, kb, ke, nunits;  // group, split, splits in use at this position, key range, K/V units
 };
 template <int HS>
 __device__ __forceinline__ EngKeys eng_keys(const EngState& st, int cu, int pos) {
     constexpr int KPP = 512 / HS;  // keys per 1-KiB piece
     EngKeys k;
-    k.part = cu < st.n_groups * st.nsplit;
+    const int n_valid = min(pos + 1, st.S);
+    // splits in use: one CU per ENG_KEYS_PER_SPLIT keys (a power of two, at most the nsplit CUs reserved per group).  A head
+    // with few keys stays on ONE CU: its partial state then needs no trip through memory to a leader (3.2 us per layer)
+    int ns = 1;
+    while (ns < st.nsplit && ns * ENG_KEYS_PER_SPLIT < n_valid) ns *= 2;
+    ns = min(ns, st.nsplit);
+    k.ns = ns;
     k.g = cu / st.nsplit;
     k.s = cu % st.nsplit;
-    const int n_valid = min(pos + 1, st.S);
-    int per = (n_valid + st.nsplit - 1) / st.nsplit;
+    k.part = cu < st.n_groups * st.nsplit && k.s < ns;
+    int per = (n_valid + ns - 1) / ns;
     per = (per + KPP - 1) / KPP * KPP;
     k.kb = min(k.s * per, n_valid);
     k.ke = min(k.kb + per, n_valid);
@@ -396,7 +412,7 @@ __device__ __forceinline__ uint32_t eng_gran_wait(const EngState& st, const EngC
                                                  uint32_t code, unsigned* nspins = nullptr) {
     unsigned spins = 0;
     while (!__all(!need || (uint32_t)(v >> 32) == c.epoch)) {
-        __builtin_amdgcn_s_sleep(2);
+        __builtin_amdgcn_s_sleep(ENG_POLL_SLEEP);
         if ((++spins & 15u) == 0) {
             if (eng_aborted(c)) break;
             if (spins > ENG_SPINS_GLOBAL || ld_err(st) != 0) {
@@ -439,9 +455,26 @@ __device__ __forceinline__ void eng_gather(const EngState& st, const EngCtx& c0,
         // each cost every hand-off its latency) until the producers are about done; the others wait on an LDS word; then
         // every wave sweeps its share until every tag matches
         if (w.cw == 0) {
+            // two polls in flight (the check of one waits for that one only: loads return in order): the arrival is seen
+            // half a round trip after it happened instead of a whole one
+            const uint64_t* gp = in + (npairs - 1);
             unsigned gs = 0;
-            (void)eng_gran_wait(st, c, in + (npairs - 1), 0, true, 0x40000000u | (uint32_t)k, &gs);
-            w.gate_spins = gs;
+            uint64_t va = ld_gran(gp), vb = 0;
+            for (;;) {
+                if (ENG_GATE_DEEP) vb = ld_gran(gp);
+                if ((uint32_t)(va >> 32) == c.epoch) break;
+                va = ld_gran(gp);
+                if (ENG_GATE_DEEP && (uint32_t)(vb >> 32) == c.epoch) break;
+                if (!ENG_GATE_DEEP) __builtin_amdgcn_s_sleep(ENG_POLL_SLEEP);
+                if ((++gs & 15u) == 0) {
+                    if (eng_aborted(c)) break;
+                    if (gs > ENG_SPINS_GLOBAL || ld_err(st) != 0) {
+                        eng_fail(st, c, 0x40000000u | (uint32_t)k);
+                        break;
+                    }
+                }
+            }
+            w.gate_spins = 2 * gs;
             if (c.lane == 0) lds_st(c.fx + EF_GATE, (uint32_t)(k + 1));
         } else {
             eng_wait_lds_ge(st, c, EF_GATE, (uint32_t)(k + 1), 0x42000000u | (uint32_t)k);
@@ -464,7 +497,7 @@ __device__ __forceinline__ void eng_gather(const EngState& st, const EngCtx& c0,
                 xv[i] = pr < npairs ? (uint32_t)gv[i] : 0u;
             }
             if (__all(ok)) break;
-            __builtin_amdgcn_s_sleep(2);
+            __builtin_amdgcn_s_sleep(ENG_POLL_SLEEP);
             if ((++spins & 15u) == 0) {
                 if (eng_aborted(c)) break;
                 if (spins > ENG_SPINS_GLOBAL || ld_err(st) != 0) {
@@ -812,7 +845,15 @@ __device__ __forceinline__ void eng_attn(const EngState& st, const EngCtx& c0, E
                 o0 += wp[c.lane % HS] * f;
                 if (HS > 64) o1 += wp[(c.lane + 64) % HS] * f;
             }
-            uint64_t* pg = op->part + ((int64_t)(ky.g * HQ + h) * st.nsplit + ky.s) * PW;
+            if (ky.ns == 1) {  // the only split: the state stays in LDS for the combine below
+                float* sg = stage + h * PW;
+                if (c.lane < HS) sg[c.lane] = o0;
+                if (HS > 64) sg[64 + c.lane] = o1;
+                if (c.lane == 0) sg[HS] = M;
+                if (c.lane == 1) sg[HS + 1] = L;
+                continue;
+            }
+            uint64_t* pg = op->part + ((int64_t)(ky.g * HQ + h) * ky.ns + ky.s) * PW;
             if (c.lane < HS) st_gran(pg + c.lane, __float_as_uint(o0), c.epoch);
             if (HS > 64) st_gran(pg + 64 + c.lane, __float_as_uint(o1), c.epoch);
             if (c.lane == 0) st_gran(pg + HS, __float_as_uint(M), c.epoch);
@@ -820,8 +861,8 @@ __device__ __forceinline__ void eng_attn(const EngState& st, const EngCtx& c0, E
         }
     }
     if (ky.s == 0) {  // the group's leader CU merges the splits into the heads: every wave fetches a share of the partial states
-        const int cnt = HQ * st.nsplit * PW;  // the group's heads lie back to back
-        const uint64_t* pg = op->part + (int64_t)ky.g * HQ * st.nsplit * PW;
+        const int cnt = HQ * ky.ns * PW;  // the group's heads lie back to back
+        const uint64_t* pg = op->part + (int64_t)ky.g * HQ * ky.ns * PW;
         constexpr int NLD = (2 * 8 * PW + 63) / 64, NPW = (NLD + ENG_NC - 1) / ENG_NC;  // HQ <= 2, nsplit <= 8
         if (!ENG_ATTN_GATE) {
         } else if (w.cw == 0) {  // one poller per CU
@@ -831,7 +872,7 @@ __device__ __forceinline__ void eng_attn(const EngState& st, const EngCtx& c0, E
             eng_wait_lds_ge(st, c, EF_GATE2, (uint32_t)(k + 1), 0x55000000u | (uint32_t)k);
         }
         unsigned spins = 0;
-        for (;;) {  // flat sweep: every load in flight at once, repeated until every tag matches
+        for (; ky.ns > 1;) {  // flat sweep: every load in flight at once, repeated until every tag matches
             uint64_t gv[NPW];
 #pragma unroll
             for (int t = 0; t < NPW; ++t) gv[t] = ld_gran(pg + min(64 * (w.cw + ENG_NC * t) + c.lane, cnt - 1));
@@ -843,7 +884,7 @@ __device__ __forceinline__ void eng_attn(const EngState& st, const EngCtx& c0, E
                 if (i < cnt) stage[i] = __uint_as_float((uint32_t)gv[t]);
             }
             if (__all(ok)) break;
-            __builtin_amdgcn_s_sleep(2);
+            __builtin_amdgcn_s_sleep(ENG_POLL_SLEEP);
             if ((++spins & 15u) == 0) {
                 if (eng_aborted(c)) break;
                 if (spins > ENG_SPINS_GLOBAL || ld_err(st) != 0) {
@@ -855,12 +896,12 @@ __device__ __forceinline__ void eng_attn(const EngState& st, const EngCtx& c0, E
         eng_cbar(st, c, w);
         if (w.cw < HQ) {  // one wave per head
             const int h = w.cw;
-            const float* sg = stage + h * st.nsplit * PW;
+            const float* sg = stage + h * ky.ns * PW;
             float M = -INFINITY;
-            for (int sp = 0; sp < st.nsplit; ++sp) M = fmaxf(M, sg[sp * PW + HS]);
+            for (int sp = 0; sp < ky.ns; ++sp) M = fmaxf(M, sg[sp * PW + HS]);
             float L = 0.f, y0 = 0.f, y1 = 0.f;
             const int dd = (2 * c.lane) % HS;
-            for (int sp = 0; sp < st.nsplit; ++sp) {
+            for (int sp = 0; sp < ky.ns; ++sp) {
                 const float ms = sg[sp * PW + HS];
                 const float f = (ms == -INFINITY) ? 0.f : __expf(ms - M);
                 L += sg[sp * PW + HS + 1] * f;
