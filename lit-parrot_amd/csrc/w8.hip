@@ -179,20 +179,22 @@ w8_prep_act_kernel(const bf16_t* __restrict__ x, int ldx, int K, float threshold
 
 // ---- multi-row calls: LLM.int8's outliers are feature DIMENSIONS of the call (arXiv:2208.07339 §3.2; bitsandbytes MatMul8bitLt:
 // idx = unique(coo_tensorA.colidx), CA[:, idx] = 0, subA = A[:, idx]): a column with an outlier in ANY row leaves the int8 product of
-// EVERY row and goes through the 16-bit product for every row.  Pass 1, one thread per column: flag, and clear the column in xq.
+// EVERY row and goes through the 16-bit product for every row.  Pass 1: flag the columns (one thread per column and chunk of rows).
 __global__ void __launch_bounds__(256)
-w8_union_cols_kernel(const float* __restrict__ xout, int8_t* __restrict__ xq, int32_t* __restrict__ colflag, int M, int K, float threshold) {
+w8_union_cols_kernel(const float* __restrict__ xout, int32_t* __restrict__ colflag, int M, int K, float threshold) {
+    // thread = one column over a chunk of 32 rows (grid.y chunks): enough workgroups to fill the chip on a 128-row prompt
     const int k = blockIdx.x * 256 + threadIdx.x;
     if (k >= K) return;
-    bool any = false;
-    for (int m = 0; m < M; ++m) any = any || fabsf(xout[(int64_t)m * K + k]) >= threshold;
-    colflag[k] = any ? 1 : 0;
-    if (any)
-        for (int m = 0; m < M; ++m) xq[(int64_t)m * K + k] = 0;
+    const int m0 = blockIdx.y * 32, m1 = min(M, m0 + 32);
+    int any = 0;
+#pragma unroll 8
+    for (int m = m0; m < m1; ++m) any |= fabsf(xout[(int64_t)m * K + k]) >= threshold ? 1 : 0;  // (no short circuit: the loads overlap)
+    if (any) atomicOr(colflag + k, 1);
 }
-// Pass 2, one workgroup per row: the ascending list of flagged columns becomes the row's outlier list (the same for every row)
+// Pass 2, one workgroup per row: the ascending list of flagged columns becomes the row's outlier list (the same for every row),
+// and those columns leave the row's int8 copy
 __global__ void __launch_bounds__(1024)
-w8_union_lists_kernel(const int32_t* __restrict__ colflag, int32_t* __restrict__ nout, int32_t* __restrict__ oidx, int K) {
+w8_union_lists_kernel(const int32_t* __restrict__ colflag, int8_t* __restrict__ xq, int32_t* __restrict__ nout, int32_t* __restrict__ oidx, int K) {
     __shared__ int scan[16];
     const int m = blockIdx.x;
     const int per = (K + 1023) / 1024;  // consecutive columns per thread: the list comes out ascending
@@ -215,7 +217,10 @@ w8_union_lists_kernel(const int32_t* __restrict__ colflag, int32_t* __restrict__
     }
     int slot = base + incl - local;
     for (int k = k0; k < k1; ++k)
-        if (colflag[k]) oidx[(int64_t)m * K + slot++] = k;
+        if (colflag[k]) {
+            oidx[(int64_t)m * K + slot++] = k;
+            xq[(int64_t)m * K + k] = 0;
+        }
     if (threadIdx.x == 0) nout[m] = total;
 }
 
@@ -801,72 +806,6 @@ w8_gemm2_kernel(const int8_t* __restrict__ A, const int8_t* __restrict__ CB, int
         }
 }
 
-// Outlier part of the prompt rows: O[row][col] = sum over the row's outlier columns k (ascending list order, as the GEMV) of
-// xout[row][k] * fp16(CB[col][k] * SCB[col] / 127).  LANES ARE ROWS: the 64 rows of a wave read the same 1-byte-wide weight row
-// CB[col][:] at their own outlier positions, so the fetches of a wave stay inside one K-byte row (and the rows of a prompt mostly
-// share their outlier columns).  With lanes as columns (first version, inside the element-wise pass) every lane touched its own
-// weight row: 256 x n_outliers cache lines per workgroup - the MLP down-projection (37 outlier columns per row on the synthetic
-// model) took 0.4 ms per launch at 512 rows.  A workgroup = 64 rows x 16 columns, transposed through LDS for the store.
-__global__ void __launch_bounds__(256)
-w8_outlier_kernel(const int8_t* __restrict__ CB, const float* __restrict__ SCB, const float* __restrict__ xout, const int32_t* __restrict__ nout,
-                  const int32_t* __restrict__ oidx, float* __restrict__ O, int M, int N, int K) {
-    __shared__ float tile[64][17];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int row = blockIdx.y * 64 + lane, rowc = min(row, M - 1);
-    const int no = row < M ? nout[rowc] : 0;
-    int no_max = no;
-#pragma unroll
-    for (int off = 32; off >= 1; off >>= 1) no_max = max(no_max, __shfl_xor(no_max, off));
-    if (__syncthreads_or(no_max > 0) == 0) return;  // nobody in this 64-row block has outliers: the element-wise pass will not read O
-    const int32_t* ip = oidx + (int64_t)rowc * K;
-    const float* xp = xout + (int64_t)rowc * K;
-    const int8_t* wrow[4];
-    float scb[4], o[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-        const int col = min((int)blockIdx.x * 16 + wave * 4 + c, N - 1);
-        wrow[c] = CB + (int64_t)col * K;
-        scb[c] = SCB[col];
-    }
-    // eight outliers at a time: their indices, then their activations and the 4 x 8 weight bytes are all in flight together (one at
-    // a time the loop was a chain of three dependent loads per outlier: 31 us per launch); the sums keep the list order
-    for (int q0 = 0; q0 < no_max; q0 += 8) {
-        int kk[8];
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {  // entries past this row's list: column 0 (a valid address; masked at the sum) - the list
-            const int k = q0 + i < no ? ip[q0 + i] : 0;  // itself is only defined up to nout[row]
-            kk[i] = min(max(k, 0), K - 1);
-        }
-        float xv[8];
-        float wv[4][8];
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            xv[i] = xp[kk[i]];
-#pragma unroll
-            for (int c = 0; c < 4; ++c) wv[c][i] = (float)wrow[c][kk[i]];
-        }
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            if (q0 + i < no) {
-#pragma unroll
-                for (int c = 0; c < 4; ++c) o[c] += xv[i] * rhalf(__fdiv_rn(__fmul_rn(wv[c][i], scb[c]), 127.0f));
-            }
-        }
-    }
-#pragma unroll
-    for (int c = 0; c < 4; ++c) tile[lane][wave * 4 + c] = o[c];
-    __syncthreads();
-    // 64 rows x 16 columns: thread t stores 4 consecutive columns of row t / 4
-    const int r = threadIdx.x >> 2, c4 = (threadIdx.x & 3) * 4;
-    const int grow = blockIdx.y * 64 + r;
-    if (grow < M) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int gcol = blockIdx.x * 16 + c4 + i;
-            if (gcol < N) O[(int64_t)grow * N + gcol] = tile[r][c4 + i];
-        }
-    }
-}
 
 // one thread per output element: sum of the K ranges (exact), mm_dequant, outlier part, epilogue (as w8_gemm_kernel / the GEMV)
 __global__ void __launch_bounds__(256)
@@ -888,10 +827,67 @@ w8_dequant_epilogue_kernel(const int32_t* __restrict__ part, const int32_t* __re
         const float scb = (pass ? SCB2 : SCB)[col];
         const float b = (bias != nullptr && pass == 0) ? bf2f(bias[col]) : 0.f;
         float v = rhalf(__fadd_rn(__fmul_rn(__fmul_rn(__fmul_rn((float)c, kMmDequant), sa), scb), b));
-        if (no > 0) v = rhalf(v + rhalf((pass ? O2 : O1)[(int64_t)row * N + col]));  // w8_outlier_kernel's sum
+        if (no > 0) v = rhalf(v + rhalf((pass ? O2 : O1)[(int64_t)row * N + col]));  // the outlier GEMM (w8_sub_gemm_kernel)
         res[pass] = v;
     }
     out[(int64_t)row * ldo + col] = apply_epilogue(epi, res[0], res[1], nullptr, residual ? residual + (int64_t)row * ldr : nullptr, col);
+}
+
+// ---- prompts: the mixed-precision part as ONE dense fp16 GEMM over the call's outlier columns (what bitsandbytes runs:
+// subA = A[:, idx], subB = fp16(CB[:, idx] * SCB / 127), out += subA @ subB^T).  The byte-gather kernel above walks the list per
+// output element; with the column rule of a multi-row call the list is the same for every row and can be long (the synthetic
+// model's MLP hidden rows: ~40 % of 11008 columns over a 128-token prompt - 64 ms of a 73 ms prefill).
+// Gather: the listed columns of A (fp16 values, exact) and of the dequantised weights into dense fp16 matrices, leading dimension
+// K (the worst case: the count lives on the device), zero-padded to a multiple of 16 columns.
+__global__ void __launch_bounds__(256)
+w8_sub_gather_kernel(const float* __restrict__ xout, const int8_t* __restrict__ CB, const float* __restrict__ SCB, const int32_t* __restrict__ nout,
+                     const int32_t* __restrict__ oidx, __half* __restrict__ subA, __half* __restrict__ subB, int M, int N, int K) {
+    const int nu = nout[0], nu16 = (nu + 15) & ~15;
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j >= nu16) return;
+    const int r = blockIdx.y;  // rows 0 .. M-1: A;  M .. M+N-1: weight rows
+    const int k = j < nu ? oidx[j] : -1;
+    if (r < M) {
+        subA[(int64_t)r * K + j] = __float2half(k >= 0 ? xout[(int64_t)r * K + k] : 0.f);
+    } else {
+        const int n = r - M;
+        const float scb = SCB[n];
+        subB[(int64_t)n * K + j] = __float2half(k >= 0 ? rhalf(__fdiv_rn(__fmul_rn((float)CB[(int64_t)n * K + k], scb), 127.0f)) : 0.f);
+    }
+}
+
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8_t;
+typedef __attribute__((ext_vector_type(16))) float w8_f32x16_t;
+
+// O[M][N] (fp32) = subA[M][nu] @ subB[N][nu]^T on v_mfma_f32_32x32x16_f16: a workgroup = 2 x 2 waves, one 32 x 32 tile each, fragments
+// straight from L2 (the operands are a few MB; 5 GFLOP at most).  fp16 x fp16 products are exact in fp32: only the summation order
+// differs from a serial sum.
+__global__ void __launch_bounds__(256)
+w8_sub_gemm_kernel(const __half* __restrict__ subA, const __half* __restrict__ subB, const int32_t* __restrict__ nout, float* __restrict__ O,
+                   int M, int N, int K) {
+    const int nu = nout[0];
+    if (nu <= 0) return;  // the element-wise pass does not read O then
+    const int nu16 = (nu + 15) & ~15;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int lr = lane & 31, lh = lane >> 5;
+    const int m0 = blockIdx.y * 64 + (wave >> 1) * 32, n0 = blockIdx.x * 64 + (wave & 1) * 32;
+    const __half* ap = subA + (int64_t)min(m0 + lr, M - 1) * K + 8 * lh;
+    const __half* bp = subB + (int64_t)min(n0 + lr, N - 1) * K + 8 * lh;
+    w8_f32x16_t acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+    for (int k0 = 0; k0 < nu16; k0 += 16) {
+        const f16x8_t af = *reinterpret_cast<const f16x8_t*>(ap + k0);
+        const f16x8_t bf = *reinterpret_cast<const f16x8_t*>(bp + k0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(af, bf, acc, 0, 0, 0);
+    }
+    // C layout of the 32x32 MFMA: column = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
+    const int col = n0 + lr;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int row = m0 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        if (row < M && col < N) O[(int64_t)row * N + col] = acc[r];
+    }
 }
 
 static int w8_gemm2_ksplit(int M, int N, int K) {
@@ -936,11 +932,13 @@ int parrot_w8_prep_act(const void* x, int ldx, int M, int K, float threshold, vo
                      K, threshold, (int8_t*)xq, (float*)xout, (float*)sca, (int32_t*)nout, (int32_t*)oidx, na);
     if (rc2 != PARROT_OK || M == 1 || !(threshold > 0.f)) return rc2;
     // several rows: the outlier columns are those of the whole call
-    rc2 = launch(K_W8_PREP_ACT, w8_union_cols_kernel, dim3((K + 255) / 256), dim3(256), 0, (hipStream_t)stream, (const float*)xout,
-                 (int8_t*)xq, (int32_t*)colflag, M, K, threshold);
+    hipError_t e = hipMemsetAsync(colflag, 0, (size_t)K * sizeof(int32_t), (hipStream_t)stream);
+    if (e != hipSuccess) return hip_fail(e, "hipMemsetAsync(colflag)");
+    rc2 = launch(K_W8_PREP_ACT, w8_union_cols_kernel, dim3((K + 255) / 256, (M + 31) / 32), dim3(256), 0, (hipStream_t)stream,
+                 (const float*)xout, (int32_t*)colflag, M, K, threshold);
     if (rc2 != PARROT_OK) return rc2;
     return launch(K_W8_PREP_ACT, w8_union_lists_kernel, dim3(M), dim3(1024), 0, (hipStream_t)stream, (const int32_t*)colflag,
-                  (int32_t*)nout, (int32_t*)oidx, K);
+                  (int8_t*)xq, (int32_t*)nout, (int32_t*)oidx, K);
 }
 
 // CB / SCB may be followed by a second weight for the SWIGLU epilogue: pass them concatenated as
@@ -1016,7 +1014,9 @@ int parrot_w8_gemv_fused(const void* CB, const void* SCB, const void* x, float t
 /* LLM.int8 prompt rows on the LDS-DMA structure: bytes of workspace parrot_w8_gemm needs (int32 sums per K range, x2 for SWIGLU) */
 int64_t parrot_w8_gemm_workspace_bytes(int M, int N, int K, int epilogue) {
     if (M <= 8 || K % 128 != 0) return 0;
-    return ((int64_t)w8_gemm2_ksplit(M, N, K) + 1) * M * N * 4 * (epilogue == PARROT_EPI_SWIGLU ? 2 : 1);  // int32 sums + fp32 outlier part
+    const int64_t nw = epilogue == PARROT_EPI_SWIGLU ? 2 : 1;
+    // int32 sums + fp32 outlier part, then the fp16 operands of the outlier GEMM: A[:, idx] (M x K at worst) and dequant(CB[:, idx])
+    return ((int64_t)w8_gemm2_ksplit(M, N, K) + 1) * M * N * 4 * nw + ((int64_t)M + nw * N) * K * 2 + 64;
 }
 
 int parrot_w8_gemm(const void* CB, const void* SCB, const void* xq, const void* xout, const void* sca, const void* nout, const void* oidx,
@@ -1047,13 +1047,20 @@ int parrot_w8_gemm(const void* CB, const void* SCB, const void* xq, const void* 
     PARROT_REQUIRE(M <= 65535, "w8_gemm: M too large");
     float* O1 = (float*)(part + (int64_t)ks * M * N * (swi ? 2 : 1));
     float* O2 = swi ? O1 + (int64_t)M * N : nullptr;
-    const dim3 ogrid((unsigned)((N + 15) / 16), (unsigned)((M + 63) / 64));
-    rc = launch(K_W8_OUTLIER, w8_outlier_kernel, ogrid, dim3(256), 0, st, (const int8_t*)CB, (const float*)SCB, (const float*)xout,
-                (const int32_t*)nout, (const int32_t*)oidx, O1, M, N, K);
+    // the mixed-precision part: gather the call's outlier columns once, one fp16 GEMM per weight
+    __half* subA = reinterpret_cast<__half*>((reinterpret_cast<uintptr_t>(O1 + (int64_t)M * N * (swi ? 2 : 1)) + 15) & ~(uintptr_t)15);
+    __half* subB = subA + (int64_t)M * K;
+    const int Ntot = swi ? 2 * N : N;
+    PARROT_REQUIRE(M + Ntot <= 65535, "w8_gemm: M + N too large for the outlier gather");
+    rc = launch(K_W8_OUTLIER, w8_sub_gather_kernel, dim3((unsigned)((K + 255) / 256), (unsigned)(M + Ntot)), dim3(256), 0, st, (const float*)xout,
+                (const int8_t*)CB, (const float*)SCB, (const int32_t*)nout, (const int32_t*)oidx, subA, subB, M, Ntot, K);
+    if (rc != PARROT_OK) return rc;
+    const dim3 ogrid((unsigned)((N + 63) / 64), (unsigned)((M + 63) / 64));
+    rc = launch(K_W8_OUTLIER, w8_sub_gemm_kernel, ogrid, dim3(256), 0, st, (const __half*)subA, (const __half*)subB, (const int32_t*)nout, O1, M, N, K);
     if (rc != PARROT_OK) return rc;
     if (swi) {
-        rc = launch(K_W8_OUTLIER, w8_outlier_kernel, ogrid, dim3(256), 0, st, CB2, SCB2, (const float*)xout, (const int32_t*)nout,
-                    (const int32_t*)oidx, O2, M, N, K);
+        rc = launch(K_W8_OUTLIER, w8_sub_gemm_kernel, ogrid, dim3(256), 0, st, (const __half*)subA, (const __half*)(subB + (int64_t)N * K),
+                    (const int32_t*)nout, O2, M, N, K);
         if (rc != PARROT_OK) return rc;
     }
     return launch(K_W8_DEQUANT, w8_dequant_epilogue_kernel, dim3((unsigned)((N + 255) / 256), (unsigned)M), dim3(256), 0, st, (const int32_t*)part,
