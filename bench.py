@@ -262,6 +262,7 @@ def cpu_baseline(cfg, mode, model, prompt_cpu, budget_s: float = 20.0, min_token
             logits = oracle(tok, S, pos)
             n += 1
             el = time.perf_counter() - t0
+            print(f"bench.py: cpu_baseline token {n} after {el:.0f} s", file=sys.stderr, flush=True)  # a long leg stays visibly alive
             if (el > budget_s and n >= min_tokens) or n >= 60:
                 break
     out.update(value=n / el, sample=f"{n} single-token decode steps after a {T0}-token prompt ({el:.1f} s), same weights, oracle/model.py on the host CPU")

@@ -1,4 +1,6 @@
-"""Diagnostic: phase stamps of the fused decode-attention kernel (workgroup 0) at Llama-2-7B shapes."""
+"""Diagnostic: phase stamps of the fused decode-attention kernel (workgroup 0) at Llama-2-7B shapes.
+Needs the diagnostic build of the library (`python lit-parrot_amd/_build.py --diag`): the stamp / tuning hooks
+(`parrot_tune_attn_stamps` ...) are not compiled into the shipped one."""
 import ctypes as C
 import sys
 from pathlib import Path

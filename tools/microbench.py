@@ -1,5 +1,7 @@
 #!/usr/bin/env python3
-"""Kernel microbenchmarks on the GPU box (not part of the product): times the weight-streaming GEMV entry points on the
+
+Needs the diagnostic build of the library (`python lit-parrot_amd/_build.py --diag`): the stamp / tuning hooks
+(`parrot_tune_w4_stamps` ...) are not compiled into the shipped one."""Kernel microbenchmarks on the GPU box (not part of the product): times the weight-streaming GEMV entry points on the
 Linear shapes of a config with rotating weight buffers (footprint > the 256 MiB Infinity Cache, so every launch streams
 from HBM like the real decode step does), and prints achieved GB/s per shape and tuning setting.
 
@@ -66,7 +68,7 @@ def main():
         import ctypes as C
         nw = torch.ones(K, dtype=torch.bfloat16, device=DEV)
         norm = C.byref(_hip.ParrotNorm(1, nw.data_ptr(), None, 1e-5, 0)) if args.norm else None
-        tune_stream = getattr(lib, "parrot_tune_w4_stream", None)
+        tune_stream = None  # the pipelined "stream" GEMV variant was retired in round 2 (kept in the history)
         variants = [(0, 0, 0), (1, 2, 1), (1, 2, 2), (1, 2, 4), (1, 4, 1), (1, 4, 2), (1, 3, 2), (1, 6, 2), (1, 8, 1)] if args.mode == "w4" and tune_stream is not None else [(0, 0, 0)]
         if args.burst_only:
             variants = [(0, 0, 0), (0, 0, 1), (0, 0, 2), (0, 0, 3), (0, 0, 4)]

@@ -1,6 +1,8 @@
 """Diagnostic: device-clock timeline of the int4 GEMV launches inside one hipGraph replay of the decode step.
 Every GEMV launch gets its own stamp buffer (3 workgroups x 8 stamps of the 100 MHz clock: entry, norm ready, dots done,
-barrier, exit); prints, per launch of the first blocks, the span and the gap to the next GEMV's entry."""
+barrier, exit); prints, per launch of the first blocks, the span and the gap to the next GEMV's entry.
+Needs the diagnostic build of the library (`python lit-parrot_amd/_build.py --diag`): the stamp / tuning hooks
+(`parrot_tune_w4_stamps` ...) are not compiled into the shipped one."""
 import argparse
 import ctypes as C
 import sys
