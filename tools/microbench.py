@@ -1,11 +1,12 @@
 #!/usr/bin/env python3
-
-Needs the diagnostic build of the library (`python lit-parrot_amd/_build.py --diag`): the stamp / tuning hooks
-(`parrot_tune_w4_stamps` ...) are not compiled into the shipped one."""Kernel microbenchmarks on the GPU box (not part of the product): times the weight-streaming GEMV entry points on the
+"""Kernel microbenchmarks on the GPU box (not part of the product): times the weight-streaming GEMV entry points on the
 Linear shapes of a config with rotating weight buffers (footprint > the 256 MiB Infinity Cache, so every launch streams
 from HBM like the real decode step does), and prints achieved GB/s per shape and tuning setting.
 
     python tools/microbench.py [--config Llama-2-7b-hf] [--mode w4|bf16] [--iters 200]
+
+The tuning sweeps and stamps need the diagnostic build of the library (`python lit-parrot_amd/_build.py --diag`): the hooks
+(`parrot_tune_w4_stamps` ...) are not compiled into the shipped one.
 """
 import argparse
 import ctypes
