@@ -296,6 +296,8 @@ def main() -> None:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}, or without a launcher")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device: the decode path has no CPU fallback")
+    if replica is None and args.devices:  # external launcher with an explicit device map (e.g. two ranks on a one-GPU box)
+        local = int(args.devices.split(",")[local])
     device = torch.device("cuda", local)
     torch.cuda.set_device(device)
     if world > 1:
