@@ -206,7 +206,10 @@ w4_gemv_kernel(const uint4* __restrict__ W, const uint4* __restrict__ W2, const 
     // (Measured alternatives: PRIME 5 - no gain; requesting the whole batch at once for small launches behind a run-time
     //  flag - 6 % SLOWER overall, because loads under a run-time condition defeat the compiler's static vmcnt
     //  bookkeeping and every wait becomes vmcnt(0).  Keep every load of this kernel unconditional.)
-    constexpr int PRIME = (RU * NW >= 8) ? 3 : 2;
+#ifndef W4_PRIME_SMALL
+#define W4_PRIME_SMALL 2
+#endif
+    constexpr int PRIME = (RU * NW >= 8) ? 3 : (RU == 4 && M == 1 && !DUAL ? W4_PRIME_SMALL : 2);
     static_assert(PRIME <= RU, "rolling window longer than a batch");
     // first row of this wave in batch T; batches past the matrix are clamped to the last row (loaded, never stored)
 #define W4_ROW0(T) (((int)blockIdx.x + (T) * (int)gridDim.x) * R + j * RU)

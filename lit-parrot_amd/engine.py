@@ -63,6 +63,9 @@ class StreamEngine:
             return "query group count / rotary width"
         if c.n_embd % 8 or c.qkv_size % 8 or c.padded_vocab_size % 8 or c.intermediate_size % 4 or c.n_embd > 16384:
             return "row counts that do not fill the 8-row blocks"
+        dev = next(model.parameters()).device
+        if dev.type != "cuda" or torch.cuda.get_device_properties(dev).multi_processor_count < ENG_WGS:
+            return f"the engine keeps {ENG_WGS} workgroups resident, one per CU: the device has fewer CUs"
         lib = _hip.load()
         nsplit = min(8, ENG_WGS // c.n_query_groups)
         b0 = lib.parrot_eng_lds_bytes(max(c.intermediate_size, c.n_embd), c.head_size, c.q_per_kv, nsplit)
@@ -149,7 +152,6 @@ class StreamEngine:
         st.arg = self.granules.data_ptr() + 8 * L * per_layer
         self.state = st
         self.n_ops = len(ops_list)
-        self.max_pos = min(cos.shape[0], tokens.numel() - 1)
         self.dbg = None
         self._keep = (tokens, pos, caches, model)
 

@@ -188,4 +188,7 @@ def generate(
             logits = sess.step()
     else:
         i = n_new
-    return sess.tokens[: T + i].to(dtype).clone()
+    out = sess.tokens[: T + i].to(dtype).clone()
+    if sess.eng is not None:
+        sess.eng.check_error()  # a bounded wait of the one-launch step gave up (e.g. fewer CUs than workgroups): fail loudly
+    return out

@@ -259,8 +259,7 @@ def test_engine_soak_is_deterministic_and_error_free():
     assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
     sess = gb.DecodeSession(model7, 64, 64, True, engine=True)
     e0 = int(sess.eng.epoch.item())
-    sess.prefill(prompt7.to(DEV))
-    L.ops.argmax_advance(sess.ws.logits if False else sess.prefill(prompt7.to(DEV)), sess.tokens, sess.pos)
+    L.ops.argmax_advance(sess.prefill(prompt7.to(DEV)), sess.tokens, sess.pos)
     for _ in range(7):
         sess.step()
     assert int(sess.eng.epoch.item()) == e0 + 7
