@@ -243,21 +243,34 @@ int parrot_argmax_advance(const void* logits, int V, int64_t* tokens, int32_t* p
 #define PARROT_ENG_ATTN 1
 #define PARROT_ENG_EPI_LOGITS 4 /* lm_head: plain bf16 logits + the CU's arg-max candidate */
 #define PARROT_ENG_WGS 256
+#define PARROT_ENG_W_E4 0
+#define PARROT_ENG_W_E16 1
 
 typedef struct parrot_eng_op {
     int32_t type;          /* PARROT_ENG_* */
-    int32_t epilogue;      /* PARROT_EPI_NONE / RESIDUAL / SWIGLU or PARROT_ENG_EPI_LOGITS */
+    int32_t epilogue;      /* PARROT_EPI_NONE / RESIDUAL / GELU / SWIGLU or PARROT_ENG_EPI_LOGITS */
     int32_t K;             /* input elements (GEMV) */
-    int32_t nblocks;       /* 8-lane-row blocks of the E4 matrix: N / 8, or N / 4 for the SwiGLU pair */
-    int32_t nq;            /* quads per block = ceil(K / 1024) */
-    int32_t buf;           /* which of the two LDS activation buffers this op's input uses (consecutive GEMVs alternate) */
-    int32_t norm_kind;     /* 0 none, 1 RMSNorm fused in front */
+    int32_t nblocks;       /* 8-row blocks of the matrix: N / 8, or N / 4 for the SwiGLU pair */
+    int32_t nq;            /* units per block = ceil(K / 1024) */
+    int32_t buf;           /* GEMV: which of the two LDS activation buffers this op's input uses (consecutive GEMVs
+                              alternate); ATTN: 1 = the previous op read buffer 0 (the attention scratch): barrier first */
+    int32_t norm_kind;     /* norm fused in front: 0 none, 1 RMSNorm, 2 LayerNorm */
     float norm_eps;
-    int32_t in_embedding;  /* the input vector is wte[tokens[pos]] (QKV of the first block) */
-    int32_t res_embedding; /* the residual is wte[tokens[pos]] (out-projection of the first block) */
-    int32_t reserved0, reserved1;
-    const void* W;         /* E4 weights */
+    int32_t in_embedding;  /* the input vector is wte[tokens[pos]] (first block) */
+    int32_t res_embedding; /* the residual is wte[tokens[pos]] (first block) */
+    int32_t wfmt;          /* PARROT_ENG_W_E4 (int4, group 128) or PARROT_ENG_W_E16 (bf16); = the state's */
+    int32_t res_in;        /* RESIDUAL: the residual is the CU's rows of 0: x (the block's input), 1: x + attention branch */
+    int32_t res_out;       /* RESIDUAL: ... and the sum becomes the CU's rows of 0 / 1 */
+    int32_t publish;       /* 1: the outputs go out as granules (`out`); 0: they stay in the CU (parallel residual: x + attn) */
+    int32_t no_gather;     /* 1: the input is already in LDS buffer `buf`: the previous Linear normalised it there (norm2_w) */
+    int32_t reserved;
+    const void* W;         /* E4 / E16 weights */
     const void* norm_w;    /* K bf16 */
+    const void* norm_b;    /* K bf16 or NULL (LayerNorm) */
+    const void* bias;      /* N bf16 or NULL (E16 only) */
+    const void* norm2_w;   /* NULL, or a second norm of the same input and kind (the MLP's norm_2 of a parallel-residual block:
+                              model.py:166-171): its result goes to the other LDS buffer, for the next op (no_gather = 1) */
+    const void* norm2_b;
     const uint64_t* in;    /* K / 2 input granules (GEMV), (q_per_kv + 2) * hs / 2 per group: the QKV vector (ATTN) */
     void* out;             /* output granules; LOGITS: V bf16, plain stores */
     uint64_t* part;        /* ATTN: n_head * nsplit * (hs + 2) fp32 granules {acc[hs], m, l} */
@@ -280,8 +293,10 @@ typedef struct parrot_eng_state {
     int32_t nsplit;             /* CUs per query group in the attention op: min(8, 256 / n_groups) */
     int32_t greedy;             /* 1: tokens[pos + 1] = argmax(logits), pos += 1 inside the launch */
     int32_t lds_buf0_bytes, lds_buf1_bytes; /* from parrot_eng_lds_bytes */
+    int32_t kmax;               /* the largest K of any op: above 11264 the build with a 6-slot ring runs */
+    int32_t wfmt;               /* PARROT_ENG_W_*: the one weight format of every Linear of the launch */
     uint64_t* arg;              /* 2 * 256 granules: every CU's arg-max candidate {value, index} */
-    uint64_t* dbg;              /* NULL, or nops * 8 words: 100 MHz stamps of workgroup 0 (diagnostic runs only) */
+    uint64_t* dbg;              /* NULL, or nops * 16 words: 100 MHz stamps of workgroup 0 (diagnostic runs only) */
     uint64_t* dbg_all;          /* NULL, or nops * 256 * 2 words: {input ready, units done} stamps of every workgroup */
 } parrot_eng_state_t;
 
@@ -291,9 +306,14 @@ int64_t parrot_e4_bytes(int N, int K, int dual);
  * SwiGLU pair or NULL */
 int parrot_e4_repack(const void* q1, const void* s1, const void* z1, const void* q2, const void* s2, const void* z2,
                      int N, int K, void* e4, void* stream);
+/* the same for bf16 weights: E16 image of an (N, K) nn.Linear weight (row-major bf16; w2 = fc_2 of a SwiGLU pair or NULL) */
+int64_t parrot_e16_bytes(int N, int K, int dual);
+int parrot_e16_repack(const void* w1, const void* w2, int N, int K, void* e16, void* stream);
 /* LDS bytes of one activation buffer for inputs of up to K elements (attention scratch for hs / q_per_kv included when
  * hs > 0); PARROT_EUNSUPPORTED when the step does not fit the CU */
 int64_t parrot_eng_lds_bytes(int K, int hs, int q_per_kv, int nsplit);
+/* dynamic LDS of the launch for these buffer sizes (ring + buffers + control area); PARROT_EUNSUPPORTED beyond 160 KiB */
+int64_t parrot_eng_lds_total(int kmax, int wfmt, int buf0_bytes, int buf1_bytes);
 /* one token, enqueued on `stream` (graph-capturable) */
 int parrot_eng_step(const parrot_eng_state_t* state_host, void* stream);
 

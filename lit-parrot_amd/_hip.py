@@ -34,14 +34,15 @@ _np = C.POINTER(ParrotNorm)
 ENG_GEMV, ENG_ATTN = 0, 1
 ENG_EPI_LOGITS = 4
 ENG_WGS = 256
+ENG_W_E4, ENG_W_E16 = 0, 1
 
 
 class EngOp(C.Structure):  # parrot_eng_op_t
     _fields_ = (
         [(n, C.c_int32) for n in ("type", "epilogue", "K", "nblocks", "nq", "buf", "norm_kind")]
         + [("norm_eps", C.c_float)]
-        + [(n, C.c_int32) for n in ("in_embedding", "res_embedding", "reserved0", "reserved1")]
-        + [(n, C.c_void_p) for n in ("W", "norm_w", "inp", "out", "part", "k_cache", "v_cache")]
+        + [(n, C.c_int32) for n in ("in_embedding", "res_embedding", "wfmt", "res_in", "res_out", "publish", "no_gather", "reserved")]
+        + [(n, C.c_void_p) for n in ("W", "norm_w", "norm_b", "bias", "norm2_w", "norm2_b", "inp", "out", "part", "k_cache", "v_cache")]
     )
 
 
@@ -50,7 +51,7 @@ class EngState(C.Structure):  # parrot_eng_state_t
         [("ops", C.c_void_p), ("nops", C.c_int32), ("d", C.c_int32)]
         + [(n, C.c_void_p) for n in ("tokens", "pos", "epoch", "err", "wte", "rope_cos", "rope_sin")]
         + [(n, C.c_int32) for n in ("n_elem", "n_groups", "q_per_kv", "hs", "S", "V", "rsqrt_mode", "nsplit", "greedy",
-                                    "lds_buf0_bytes", "lds_buf1_bytes")]
+                                    "lds_buf0_bytes", "lds_buf1_bytes", "kmax", "wfmt")]
         + [(n, C.c_void_p) for n in ("arg", "dbg", "dbg_all")]
     )
 
@@ -88,7 +89,10 @@ SIGNATURES = {
     "parrot_attn_prefill": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _i, _vp]),
     "parrot_e4_bytes": (_i64, [_i, _i, _i]),
     "parrot_e4_repack": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp]),
+    "parrot_e16_bytes": (_i64, [_i, _i, _i]),
+    "parrot_e16_repack": (_i, [_vp, _vp, _i, _i, _vp, _vp]),
     "parrot_eng_lds_bytes": (_i64, [_i, _i, _i, _i]),
+    "parrot_eng_lds_total": (_i64, [_i, _i, _i, _i]),
     "parrot_eng_step": (_i, [C.POINTER(EngState), _vp]),
     "parrot_embedding": (_i, [_vp, _i, _vp, _vp, _i, _vp, _i, _vp]),
     "parrot_gptq_block": (_i, [_vp, _i, _i, _i, _i, _vp, _i, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),

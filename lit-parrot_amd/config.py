@@ -130,6 +130,8 @@ _TABLE = [
     _falcon("falcon-40b-instruct", 60, 128, 8192, 8),
     # tiny shapes of each family (tests and smoke); head sizes the attention kernel is built for
     _neox("test", "tiny-neox", block_size=128, vocab_size=500, padding_multiple=64, n_layer=2, n_head=4, n_embd=128),
+    _neox("test", "tiny-neox-hs64", block_size=128, vocab_size=500, padding_multiple=64, n_layer=2, n_head=4, n_embd=256),
+    _neox("test", "tiny-neox-hs128", block_size=128, vocab_size=500, padding_multiple=64, n_layer=2, n_head=3, n_embd=384),
     dict(_llama2("tiny-llama", 2, 2, 128, 352), org="test", block_size=128, vocab_size=500),
     dict(_llama2("tiny-llama-gqa", 2, 4, 256, 352, n_query_groups=2), org="test", block_size=128, vocab_size=500),
     dict(_llama2("tiny-llama-hs128", 2, 2, 256, 416), org="test", block_size=128, vocab_size=500),

@@ -47,16 +47,42 @@ namespace parrot {
 #ifndef ENG_ATTN_GATE
 #define ENG_ATTN_GATE 0
 #endif
+#ifndef ENG_STAMPS
+#ifdef PARROT_DIAG
+#define ENG_STAMPS 1
+#else
+#define ENG_STAMPS 0
+#endif
+#endif
+#ifndef ENG_SPIN_MODE
+#define ENG_SPIN_MODE (-1)  // -1: by weight format (bf16: waiting waves drop their priority, +0.8 %; int4: plain spin, +0.7 %)
+#endif
+#ifndef ENG_AB_NOGSTAMP
+#define ENG_AB_NOGSTAMP 0
+#endif
 constexpr int ENG_WGS = PARROT_ENG_WGS;
 constexpr int ENG_KEYS_PER_SPLIT = ENG_KEYS_PER_SPLIT_V;  // keys of a head that one CU attends over before a second CU joins
-constexpr int ENG_NC = 15;                // consumer waves
-constexpr int ENG_THREADS = (ENG_NC + 1) * 64;
-constexpr int ENG_NSLOT = 7;              // ring slots
+constexpr int ENG_NC = 15;                // consumer waves at most (EngCfg::NC)
+constexpr int ENG_THREADS = 16 * 64;
 constexpr int ENG_SLOT_BYTES = 17 * 1024;
 constexpr int ENG_META_OFF = 16 * 1024;   // the metadata piece of a slot, in LDS
-constexpr int ENG_MAXG = 6;               // input groups (128 elements) per consumer wave: K <= 15 * 6 * 128 = 11520
-constexpr int ENG_MAXQ = 11;              // quads per block: K <= 11264
 constexpr int ENG_RED = 16;               // block result buffers in flight
+// Two builds of the kernel.  BIG = 0: inputs of up to 11264 elements, a ring of 7 slots (the Llama-2-7B family);
+// BIG = 1: inputs of up to 16384 elements (StableLM's MLP), whose LDS image leaves room for 6 slots.
+template <int BIG, int WFMT>
+struct EngCfg {
+    static constexpr int WF = WFMT;             // PARROT_ENG_W_E4 / _E16: one weight format per launch
+    // bf16 weights: the arithmetic per byte is a quarter of int4's, the stream is the limit - two loader waves (ring slots
+    // alternate between them: twice the LDS-DMA in flight, vmcnt counts per wave) and 14 consumer waves
+    static constexpr int NLOAD = WFMT == PARROT_ENG_W_E16 ? 2 : 1;
+    static constexpr int SPIN = ENG_SPIN_MODE >= 0 ? ENG_SPIN_MODE : (WFMT == PARROT_ENG_W_E16 ? 1 : 0);  // consumer barrier: how waiting waves wait
+    static constexpr int NC = 16 - NLOAD;       // consumer waves
+    static constexpr int NSLOT = (BIG || NLOAD == 2) ? 6 : 7;  // ring slots (even with two loaders: a slot keeps its loader)
+    static constexpr int MAXG = (BIG ? 9 : 6) + (NLOAD - 1);   // input groups (128 elements) per consumer wave: K <= NC * MAXG * 128
+    static constexpr int MAXQ = BIG ? 16 : 11;  // units (1024 input columns) per block: K <= 1024 * MAXQ
+};
+constexpr int ENG_MAXQ_BIG = EngCfg<1, 0>::MAXQ, ENG_MAXQ_STD = EngCfg<0, 0>::MAXQ, ENG_MAXG_BIG = EngCfg<1, 0>::MAXG;
+constexpr int ENG_NSLOT_BIG = EngCfg<1, 0>::NSLOT, ENG_NSLOT_STD = EngCfg<0, 0>::NSLOT;
 constexpr int ENG_GROUP_STRIDE = 272;     // LDS bytes per 128-element group of an activation buffer (256 + 16: bank spread)
 constexpr int ENG_MAXFLY = ENG_MAXFLY_V;             // ring slots with LDS-DMA in flight (vmcnt counts at most 63 operations)
 constexpr int ENG_THIN_PIECES = ENG_THIN_PIECES_V;  // prefetch slots (ops behind a hand-off) are issued with at most this many pieces outstanding
@@ -68,23 +94,25 @@ typedef parrot_eng_state_t EngState;
 
 // fixed LDS area behind the ring and the two activation buffers (byte offsets inside it)
 constexpr int EF_XS = 0;                                  // [2][128] float: per-group sums of the activations
-constexpr int EF_RED = EF_XS + 2 * 128 * 4;               // [ENG_RED][ENG_MAXQ][8] float
-constexpr int EF_ROPE = EF_RED + ENG_RED * ENG_MAXQ * 8 * 4;  // [2][128] float: cos / sin row of this position
-constexpr int EF_RESID = EF_ROPE + 2 * 128 * 4;           // [64] float: the CU's own rows of the residual stream
-constexpr int EF_STAT = EF_RESID + 64 * 4;                // [16] float
-constexpr int EF_BESTV = EF_STAT + 64;                    // [16] float
+constexpr int EF_ROPE = EF_XS + 2 * 128 * 4;              // [2][128] float: cos / sin row of this position
+constexpr int EF_RESID = EF_ROPE + 2 * 128 * 4;           // [2][64] float: the CU's own rows of the residual stream (x; x + attention)
+constexpr int EF_REDB = EF_RESID + 2 * 64 * 4;            // [ENG_RED][8] float: the Linear's bias of a block's rows
+constexpr int EF_STAT = EF_REDB + ENG_RED * 8 * 4;        // [2][16] float: the waves' partial norm statistics
+constexpr int EF_BESTV = EF_STAT + 128;                   // [16] float
 constexpr int EF_BESTI = EF_BESTV + 64;                   // [16] int
 constexpr int EF_FULL = EF_BESTI + 64;                    // [8] u32: sequence number + 1 of the slot's landed contents
 constexpr int EF_CONS = EF_FULL + 32;                     // [8] u32: units consumed from the ring slot, cumulative
 constexpr int EF_EXP = EF_CONS + 32;                      // [8] u32 (loader): units issued into the ring slot, cumulative
 constexpr int EF_NPQ = EF_EXP + 32;                       // [8] u32 (loader): pieces of the issued, unpublished slots
-constexpr int EF_DONE = EF_NPQ + 32;                      // [ENG_RED] u32: quads finished of a block
+constexpr int EF_DONE = EF_NPQ + 32;                      // [ENG_RED] u32: units finished of a block
 constexpr int EF_CB = EF_DONE + ENG_RED * 4;              // consumer barrier counter
 constexpr int EF_ABORT = EF_CB + 4;
 constexpr int EF_GATE = EF_ABORT + 4;                     // op index + 1 whose input producers were seen to be done (one poller per CU)
 constexpr int EF_GATE2 = EF_GATE + 4;                     // the same for the attention leader's wait for the partial states
 constexpr int EF_CUR = EF_GATE2 + 4;                      // index of the op whose input the consumers have (loader: how urgent a slot is)
-constexpr int EF_BYTES = EF_CUR + 8;
+constexpr int EF_RED = EF_CUR + 16;                       // [ENG_RED][MAXQ][8] float: the units' partial sums of a block's rows
+template <class CF>
+constexpr int ef_bytes() { return EF_RED + ENG_RED * CF::MAXQ * 8 * 4; }
 
 typedef __attribute__((address_space(3))) uint32_t lds_u32_t;
 typedef const __attribute__((address_space(4))) uint32_t* cst_cu32_t;
@@ -139,8 +167,22 @@ __device__ __forceinline__ void eng_dma(const void* gsrc, unsigned lds_dst_unifo
                      : "=&s"(keep) : "v"(gsrc), "s"(lds_dst_uniform) : "memory");
 }
 
+// v[lane] = value (both wave-uniform; the lane select goes through m0: one SGPR operand per VALU instruction)
+__device__ __forceinline__ void eng_writelane(int& v, int value, int lane) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %1, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tv_writelane_b32 %0, %2, m0\n\ts_mov_b32 m0, %1"
+                 : "+v"(v), "=&s"(keep) : "s"(value), "s"(lane));
+}
+
 // wait until at most n of this wave's vector-memory operations are outstanding (n is wave-uniform, 0..63)
+#ifndef ENG_VMCNT_CALL
+#define ENG_VMCNT_CALL 0
+#endif
+#if ENG_VMCNT_CALL
+__device__ __attribute__((noinline)) void wait_vmcnt(int n) {  // one copy of the 64-case switch (the loader calls it from ten places)
+#else
 __device__ __forceinline__ void wait_vmcnt(int n) {
+#endif
 #define ENG_VM(N) case N: asm volatile("s_waitcnt vmcnt(%0)" ::"i"(N) : "memory"); break;
 #define ENG_VM4(N) ENG_VM(N) ENG_VM(N + 1) ENG_VM(N + 2) ENG_VM(N + 3)
 #define ENG_VM16(N) ENG_VM4(N) ENG_VM4(N + 4) ENG_VM4(N + 8) ENG_VM4(N + 12)
@@ -223,23 +265,41 @@ __device__ __forceinline__ void eng_wait_lds_ge(const EngState& st, const EngCtx
 }
 
 // the same without sleeping between polls: for waits that are a few hundred cycles long (the consumer barrier)
+template <int MODE>
 __device__ __forceinline__ void eng_wait_lds_ge_tight(const EngState& st, const EngCtx& c, int off, uint32_t target, uint32_t code) {
     unsigned spins = 0;
+    if (MODE == 1) __builtin_amdgcn_s_setprio(0);  // the waves still working share this SIMD: they go first
     while ((int32_t)(lds_ld(c.fx + off) - target) < 0) {
+        if (MODE == 2) __builtin_amdgcn_s_sleep(1);
         if ((++spins & 255u) == 0) {
-            if (eng_aborted(c)) return;
+            if (eng_aborted(c)) break;
             if (spins > 4 * ENG_SPINS_LDS) {
                 eng_fail(st, c, code);
-                return;
+                break;
             }
         }
     }
+    if (MODE == 1) __builtin_amdgcn_s_setprio(1);
 }
 
-// blocks of op that CU c owns: [b0, b1)
-__device__ __forceinline__ void eng_block_range(int nblocks, int cu, int& b0, int& b1) {
-    b0 = (int)(((int64_t)cu * nblocks) / ENG_WGS);
-    b1 = (int)(((int64_t)(cu + 1) * nblocks) / ENG_WGS);
+// blocks of an op that CU c owns: local block bl = 0 .. nb - 1 is block bs + bl * bstep of the matrix.
+// Contiguous ranges.  (ENG_CYCLIC = 1, an experiment: block b belongs to CU b % 256, so that at any moment the 256 loaders
+// read neighbouring pieces of the matrix.  Measured: +0.5 % on StableLM-3B bf16, -5 % on Llama-2-7B int4 - the 8 outputs
+// of a block are a quarter of a cache line, and neighbouring blocks now publish from different XCDs.)
+#ifndef ENG_CYCLIC
+#define ENG_CYCLIC 0
+#endif
+__device__ __forceinline__ void eng_block_range(int nblocks, int cu, int& bs, int& nb, int& bstep) {
+    if (ENG_CYCLIC) {
+        bs = cu;
+        nb = (nblocks - cu + ENG_WGS - 1) / ENG_WGS;
+        if (nb < 0) nb = 0;
+        bstep = ENG_WGS;
+    } else {
+        bs = (int)(((int64_t)cu * nblocks) / ENG_WGS);
+        nb = (int)(((int64_t)(cu + 1) * nblocks) / ENG_WGS) - bs;
+        bstep = 1;
+    }
 }
 // key range of CU c in an attention op: group g, split s; keys [kb, ke) of the n_valid admitted slots
 struct EngKeys {
@@ -268,19 +328,29 @@ __device__ __forceinline__ EngKeys eng_keys(const EngState& st, int cu, int pos)
     return k;
 }
 
-// ------------------------------------------------------------------------------------------ the loader wave
-template <int HS>
-__device__ __forceinline__ void eng_loader(const EngState& st, const EngCtx& c) {
+// ------------------------------------------------------------------------------------------ the loader wave(s)
+// Loader li of CF::NLOAD walks every slot of the CU's stream and issues the ones with sequence number % NLOAD == li.
+template <class CF, int HS>
+__device__ __forceinline__ void eng_loader(const EngState& st, const EngCtx& c, int li) {
     constexpr int KPP = 512 / HS;
+    constexpr int NSLOT = CF::NSLOT, NLOAD = CF::NLOAD;
+    static_assert(NLOAD == 1 || NSLOT % NLOAD == 0, "a ring slot must keep its loader");
     const unsigned ring_lds = (unsigned)(uintptr_t)c.ring;
-    int seq = 0, pub = 0, inflight = 0;
+    int seq = 0;                  // sequence number of the next slot of the stream (all loaders count alike)
+    int mine = 0, pub = 0;        // own slots issued / announced
+    int inflight = 0;             // own pieces in flight
     __builtin_amdgcn_s_setprio(3);  // a handful of instructions per slot: never behind the consumers' arithmetic
 
+    // the loader's own bookkeeping lives in two registers, one lane per entry (an LDS round trip per look-up was a fifth
+    // of the time the loader has per slot at full stream rate): exp_v[ring slot] = units issued into it so far;
+    // npq_v[own slot number % 8] = pieces of the issued, unannounced slots
+    int exp_v = 0, npq_v = 0;
     auto publish_oldest = [&]() {
-        const int np = (int)lds_ld(c.fx + EF_NPQ + (pub & 7) * 4);
+        const int np = __builtin_amdgcn_readlane(npq_v, pub & 7);
         wait_vmcnt(inflight - np);
         inflight -= np;
-        lds_st(c.fx + EF_FULL + (pub % ENG_NSLOT) * 4, (uint32_t)(pub + 1));
+        const int g = li + pub * NLOAD;  // its sequence number
+        lds_st(c.fx + EF_FULL + (g % NSLOT) * 4, (uint32_t)(g + 1));
         ++pub;
     };
     // wait for ring slot seq % NSLOT to be free; returns the cumulative unit count it had.
@@ -289,60 +359,101 @@ __device__ __forceinline__ void eng_loader(const EngState& st, const EngCtx& c) 
     // urgent and go out three deep; slots of ops whose input is still outstanding are prefetch: one slot in flight, so that
     // the epilogue stores of the current op and the polls of the next one pass quickly.
     auto acquire = [&](int np, int k) -> uint32_t {
-        const int r = seq % ENG_NSLOT;
-        const uint32_t target = lds_ld(c.fx + EF_EXP + r * 4);
+        const int r = seq % NSLOT;
+        const uint32_t target = (uint32_t)__builtin_amdgcn_readlane(exp_v, r);
         if (lds_ld(c.fx + EF_CONS + r * 4) != target) {
-            while (pub < seq) publish_oldest();  // never sleep on a free slot with landed data unannounced
+            while (pub < mine) publish_oldest();  // never sleep on a free slot with landed data unannounced
             eng_wait_lds_ge(st, c, EF_CONS + r * 4, target, 0x10000000u | (uint32_t)seq);
         }
-        while (seq - pub >= ENG_MAXFLY || inflight + np > 60) publish_oldest();
+        while (mine - pub >= ENG_MAXFLY || inflight + np > 60) publish_oldest();
         if (k > (int)lds_ld(c.fx + EF_CUR))
-            while (inflight > ENG_THIN_PIECES && pub < seq) publish_oldest();
+            while (inflight > ENG_THIN_PIECES && pub < mine) publish_oldest();
         return target;
     };
     auto commit = [&](uint32_t target, int np, int nunits) {
-        const int r = seq % ENG_NSLOT;
-        lds_st(c.fx + EF_EXP + r * 4, target + (uint32_t)nunits);
-        lds_st(c.fx + EF_NPQ + (seq & 7) * 4, (uint32_t)np);
+        eng_writelane(exp_v, __builtin_amdgcn_readfirstlane((int)(target + (uint32_t)nunits)), seq % NSLOT);
+        eng_writelane(npq_v, np, mine & 7);
         inflight += np;
+        ++mine;
         ++seq;
     };
+    auto own = [&]() -> bool { return NLOAD == 1 || seq % NLOAD == li; };
 
     for (int k = 0; k < st.nops; ++k) {
         const EngOp opv = eng_fetch_op(st.ops, k);
         const EngOp* op = &opv;
-        if (st.dbg != nullptr && c.cu == 0 && c.lane == 0) {  // diagnostic: when the loader reaches the op, and what it has announced by then
-            st.dbg[k * 8 + 4] = __builtin_amdgcn_s_memrealtime();
-            st.dbg[k * 8 + 5] = (uint64_t)seq | ((uint64_t)pub << 32);
+        if ((ENG_STAMPS && st.dbg != nullptr) && c.cu == 0 && c.lane == 0 && li == 0) {  // diagnostic: when the loader reaches the op, and what it has announced by then
+            st.dbg[k * 16 + 4] = __builtin_amdgcn_s_memrealtime();
+            st.dbg[k * 16 + 5] = (uint64_t)seq | ((uint64_t)(li + pub * NLOAD) << 32);
         }
         if (op->type == PARROT_ENG_GEMV) {
             if (op->norm_kind != 0) {
-                // the norm's weights (K bf16, constants) ride the ring too: a plain load of them sat in front of the
-                // hand-off polls (vmcnt is in order) with an HBM miss of 1 - 2 us; every consumer wave reads its share
-                const int np = (op->K * 2 + 1023) >> 10;
-                const uint32_t target = acquire(np, k);
-                const unsigned dst = __builtin_amdgcn_readfirstlane(ring_lds + (unsigned)((seq % ENG_NSLOT) * ENG_SLOT_BYTES));
-                const int64_t last = (int64_t)op->K * 2 - 16;
-                for (int j = 0; j < np; ++j)
-                    eng_dma<false>(reinterpret_cast<const unsigned char*>(op->norm_w) + min((int64_t)j * 1024 + c.lane * 16, last),
-                                   dst + (unsigned)(j * 1024));
-                commit(target, np, ENG_NC);
-            }
-            int b0, b1;
-            eng_block_range(op->nblocks, c.cu, b0, b1);
-            const int nq = op->nq, spb = (nq + 3) >> 2;
-            const int64_t block_bytes = (int64_t)(4 * nq + spb) * 1024;
-            for (int b = b0; b < b1; ++b) {
-                for (int sib = 0; sib < spb; ++sib) {
-                    const int nqs = min(4, nq - 4 * sib);
-                    const int np = 4 * nqs + 1;
+                // the norm's weights (K bf16, constants; LayerNorm: the bias behind them) ride the ring too: a plain load of
+                // them sat in front of the hand-off polls (vmcnt is in order) with an HBM miss of 1 - 2 us; every consumer
+                // wave reads its share
+                // (a second norm of the same input - the MLP's of a parallel-residual block - follows in a slot of its own)
+                for (int which = 0; which < (op->norm2_w != nullptr ? 2 : 1); ++which) {
+                    if (!own()) {
+                        ++seq;
+                        continue;
+                    }
+                    const unsigned char* nw = reinterpret_cast<const unsigned char*>(which ? op->norm2_w : op->norm_w);
+                    const unsigned char* nb = reinterpret_cast<const unsigned char*>(which ? op->norm2_b : op->norm_b);
+                    const int npw = (op->K * 2 + 1023) >> 10;
+                    const int np = nb != nullptr ? 2 * npw : npw;
                     const uint32_t target = acquire(np, k);
-                    const unsigned char* src = reinterpret_cast<const unsigned char*>(op->W) + (int64_t)b * block_bytes +
-                                               (int64_t)sib * ENG_SLOT_BYTES + c.lane * 16;
-                    const unsigned dst = __builtin_amdgcn_readfirstlane(ring_lds + (unsigned)((seq % ENG_NSLOT) * ENG_SLOT_BYTES));
-                    for (int j = 0; j < np - 1; ++j) eng_dma<true>(src + j * 1024, dst + (unsigned)(j * 1024));
-                    eng_dma<true>(src + (np - 1) * 1024, dst + (unsigned)ENG_META_OFF);
-                    commit(target, np, nqs);
+                    const unsigned dst = __builtin_amdgcn_readfirstlane(ring_lds + (unsigned)((seq % NSLOT) * ENG_SLOT_BYTES));
+                    const int64_t last = (int64_t)op->K * 2 - 16;
+                    for (int j = 0; j < npw; ++j) eng_dma<false>(nw + min((int64_t)j * 1024 + c.lane * 16, last), dst + (unsigned)(j * 1024));
+                    if (nb != nullptr)
+                        for (int j = 0; j < npw; ++j)
+                            eng_dma<false>(nb + min((int64_t)j * 1024 + c.lane * 16, last), dst + (unsigned)((npw + j) * 1024));
+                    commit(target, np, CF::NC);
+                }
+            }
+            int bs, nb, bstep;
+            eng_block_range(op->nblocks, c.cu, bs, nb, bstep);
+            const int nq = op->nq;
+            if (CF::WF == PARROT_ENG_W_E16) {
+                // bf16: a slot is one unit = 16 pieces (8 rows x 1024 columns); the first slot of a block carries the block's
+                // 8 bias values (every lane fetches the same 16 bytes) where the int4 layout has its metadata
+                for (int bl = 0; bl < nb; ++bl) {
+                    const int b = bs + bl * bstep;
+                    for (int Q = 0; Q < nq; ++Q) {
+                        if (!own()) {
+                            ++seq;
+                            continue;
+                        }
+                        const bool wb = Q == 0 && op->bias != nullptr;
+                        const int np = wb ? 17 : 16;
+                        const uint32_t target = acquire(np, k);
+                        const unsigned char* src = reinterpret_cast<const unsigned char*>(op->W) + ((int64_t)b * nq + Q) * 16384 + c.lane * 16;
+                        const unsigned dst = __builtin_amdgcn_readfirstlane(ring_lds + (unsigned)((seq % NSLOT) * ENG_SLOT_BYTES));
+                        for (int j = 0; j < 16; ++j) eng_dma<true>(src + j * 1024, dst + (unsigned)(j * 1024));
+                        if (wb) eng_dma<false>(reinterpret_cast<const unsigned char*>(op->bias) + (int64_t)b * 16, dst + (unsigned)ENG_META_OFF);
+                        commit(target, np, 1);
+                    }
+                }
+            } else {
+                const int spb = (nq + 3) >> 2;
+                const int64_t block_bytes = (int64_t)(4 * nq + spb) * 1024;
+                for (int bl = 0; bl < nb; ++bl) {
+                    const int b = bs + bl * bstep;
+                    for (int sib = 0; sib < spb; ++sib) {
+                        if (!own()) {
+                            ++seq;
+                            continue;
+                        }
+                        const int nqs = min(4, nq - 4 * sib);
+                        const int np = 4 * nqs + 1;
+                        const uint32_t target = acquire(np, k);
+                        const unsigned char* src = reinterpret_cast<const unsigned char*>(op->W) + (int64_t)b * block_bytes +
+                                                   (int64_t)sib * ENG_SLOT_BYTES + c.lane * 16;
+                        const unsigned dst = __builtin_amdgcn_readfirstlane(ring_lds + (unsigned)((seq % NSLOT) * ENG_SLOT_BYTES));
+                        for (int j = 0; j < np - 1; ++j) eng_dma<true>(src + j * 1024, dst + (unsigned)(j * 1024));
+                        eng_dma<true>(src + (np - 1) * 1024, dst + (unsigned)ENG_META_OFF);
+                        commit(target, np, nqs);
+                    }
                 }
             }
         } else {
@@ -351,9 +462,13 @@ __device__ __forceinline__ void eng_loader(const EngState& st, const EngCtx& c) 
             const unsigned char* kg = reinterpret_cast<const unsigned char*>(op->k_cache) + (int64_t)ky.g * grp_bytes;
             const unsigned char* vg = reinterpret_cast<const unsigned char*>(op->v_cache) + (int64_t)ky.g * grp_bytes;
             for (int u0 = 0; u0 < ky.nunits; u0 += 8) {
+                if (!own()) {
+                    ++seq;
+                    continue;
+                }
                 const int nu = min(8, ky.nunits - u0);
                 const uint32_t target = acquire(2 * nu, k);
-                const unsigned dst = __builtin_amdgcn_readfirstlane(ring_lds + (unsigned)((seq % ENG_NSLOT) * ENG_SLOT_BYTES));
+                const unsigned dst = __builtin_amdgcn_readfirstlane(ring_lds + (unsigned)((seq % NSLOT) * ENG_SLOT_BYTES));
                 for (int uu = 0; uu < nu; ++uu) {
                     // rows past the group's last one are clamped to it (loaded, never used)
                     const int64_t off = min((int64_t)(ky.kb + (u0 + uu) * KPP) * HS * 2 + c.lane * 16, grp_bytes - 16);
@@ -364,7 +479,7 @@ __device__ __forceinline__ void eng_loader(const EngState& st, const EngCtx& c) 
             }
         }
     }
-    while (pub < seq) publish_oldest();
+    while (pub < mine) publish_oldest();
 }
 
 // ------------------------------------------------------------------------------------------ consumer side
@@ -380,29 +495,35 @@ struct EngCons {
 };
 
 // barrier over the consumer waves (the loader never joins)
+template <class CF>
 __device__ __forceinline__ void eng_cbar(const EngState& st, const EngCtx& c, EngCons& w) {
     lds_drain();
-    w.cb_gen += ENG_NC;
+    w.cb_gen += CF::NC;
     if (c.lane == 0) lds_add(c.fx + EF_CB, 1u);
-    eng_wait_lds_ge_tight(st, c, EF_CB, w.cb_gen, 0x20000000u | w.cb_gen);
+    eng_wait_lds_ge_tight<CF::SPIN>(st, c, EF_CB, w.cb_gen, 0x20000000u | w.cb_gen);
 }
+template <class CF>
 __device__ __forceinline__ void eng_wait_full(const EngState& st, const EngCtx& c, EngCons& w, int seq) {
-    if (st.dbg != nullptr) {
+    if ((ENG_STAMPS && st.dbg != nullptr)) {
         const uint64_t t0 = __builtin_amdgcn_s_memrealtime();
-        eng_wait_lds_ge(st, c, EF_FULL + (seq % ENG_NSLOT) * 4, (uint32_t)(seq + 1), 0x30000000u | (uint32_t)seq);
+        eng_wait_lds_ge(st, c, EF_FULL + (seq % CF::NSLOT) * 4, (uint32_t)(seq + 1), 0x30000000u | (uint32_t)seq);
         w.waited += __builtin_amdgcn_s_memrealtime() - t0;
         return;
     }
-    eng_wait_lds_ge(st, c, EF_FULL + (seq % ENG_NSLOT) * 4, (uint32_t)(seq + 1), 0x30000000u | (uint32_t)seq);
+    eng_wait_lds_ge(st, c, EF_FULL + (seq % CF::NSLOT) * 4, (uint32_t)(seq + 1), 0x30000000u | (uint32_t)seq);
 }
+template <class CF>
 __device__ __forceinline__ void eng_release(const EngCtx& c, int seq) {
     lds_drain();  // this wave's reads of the slot have returned
-    if (c.lane == 0) lds_add(c.fx + EF_CONS + (seq % ENG_NSLOT) * 4, 1u);
+    if (c.lane == 0) lds_add(c.fx + EF_CONS + (seq % CF::NSLOT) * 4, 1u);
 }
 __device__ __forceinline__ void eng_stamp(const EngState& st, const EngCtx& c, const EngCons& w, int k, int i) {
-    if (st.dbg != nullptr && c.cu == 0 && w.cw == 0 && c.lane == 0) st.dbg[k * 8 + i] = __builtin_amdgcn_s_memrealtime();
+#if ENG_AB_NOGSTAMP
+    if (i >= 8) return;
+#endif
+    if ((ENG_STAMPS && st.dbg != nullptr) && c.cu == 0 && w.cw == 0 && c.lane == 0) st.dbg[k * 16 + i] = __builtin_amdgcn_s_memrealtime();
     // every CU's {input ready, own units done} times of every op (the 100 MHz clock is chip-wide): who is late
-    if (st.dbg_all != nullptr && (i == 1 || i == 2) && w.cw == 0 && c.lane == 0)
+    if ((ENG_STAMPS && st.dbg_all != nullptr) && (i == 1 || i == 2) && w.cw == 0 && c.lane == 0)
         st.dbg_all[((int64_t)k * ENG_WGS + c.cu) * 2 + (i - 1)] = __builtin_amdgcn_s_memrealtime();
 }
 
@@ -427,6 +548,7 @@ __device__ __forceinline__ uint32_t eng_gran_wait(const EngState& st, const EngC
 }
 
 // ---- input vector of a GEMV op -> LDS activation buffer (normalised bf16, per-group sums)
+template <class CF>
 __device__ __forceinline__ void eng_gather(const EngState& st, const EngCtx& c0, EngCons& w, const EngOp* op, int k) {
     EngCtx c = c0;
     asm volatile("" : "+v"(c.lane));  // an opaque copy per op: addresses derived from the lane are not hoisted out of the op loop
@@ -434,14 +556,12 @@ __device__ __forceinline__ void eng_gather(const EngState& st, const EngCtx& c0,
     const int npairs = K >> 1;
     const int ngr = (K + 127) >> 7;
     const int ngr_pad = op->nq * 8;
-    unsigned char* buf = op->buf ? c.buf1 : c.buf0;
-    float* xs = reinterpret_cast<float*>(c.fx + EF_XS) + op->buf * 128;
-    uint32_t xv[ENG_MAXG];
+    uint32_t xv[CF::MAXG];
     if (op->in_embedding) {
         glb_cu32_t e32 = (glb_cu32_t)c.emb;
 #pragma unroll
-        for (int i = 0; i < ENG_MAXG; ++i) {
-            const int g = w.cw + ENG_NC * i;
+        for (int i = 0; i < CF::MAXG; ++i) {
+            const int g = w.cw + CF::NC * i;
             xv[i] = 0;
             if (g < ngr) {
                 const int pr = 64 * g + c.lane;
@@ -482,17 +602,17 @@ __device__ __forceinline__ void eng_gather(const EngState& st, const EngCtx& c0,
         eng_stamp(st, c, w, k, 6);
         unsigned spins = 0;
         for (;;) {
-            uint64_t gv[ENG_MAXG];
+            uint64_t gv[CF::MAXG];
 #pragma unroll
-            for (int i = 0; i < ENG_MAXG; ++i) {
-                const int g = w.cw + ENG_NC * i;
+            for (int i = 0; i < CF::MAXG; ++i) {
+                const int g = w.cw + CF::NC * i;
                 gv[i] = (uint64_t)c.epoch << 32;
                 if (g < ngr) gv[i] = ld_gran(in + min(64 * g + c.lane, npairs - 1));
             }
             bool ok = true;
 #pragma unroll
-            for (int i = 0; i < ENG_MAXG; ++i) {
-                const int pr = 64 * (w.cw + ENG_NC * i) + c.lane;
+            for (int i = 0; i < CF::MAXG; ++i) {
+                const int pr = 64 * (w.cw + CF::NC * i) + c.lane;
                 ok = ok && ((uint32_t)(gv[i] >> 32) == c.epoch || pr >= npairs);
                 xv[i] = pr < npairs ? (uint32_t)gv[i] : 0u;
             }
@@ -514,121 +634,185 @@ __device__ __forceinline__ void eng_gather(const EngState& st, const EngCtx& c0,
     na.eps = op->norm_eps;
     na.rsqrt_mode = st.rsqrt_mode;
     na.d = K;
-    if (na.kind == 1) {
+    float mean = 0.f;
+    if (na.kind != 0) {
+        // row statistics: every wave's partial sum -> LDS, summed in wave order by everyone (LayerNorm: mean first, then
+        // the squared deviations, two passes as norm.hip)
+        float* stat = reinterpret_cast<float*>(c.fx + EF_STAT);
         float s1 = 0.f;
 #pragma unroll
-        for (int i = 0; i < ENG_MAXG; ++i) s1 += norm_stat1(xv[i], 1);  // zero pairs add nothing
+        for (int i = 0; i < CF::MAXG; ++i) s1 += norm_stat1(xv[i], na.kind);  // zero pairs add nothing
         s1 = wave_sum_to_lane63(s1);
-        if (c.lane == 63) reinterpret_cast<float*>(c.fx + EF_STAT)[w.cw] = s1;
-        eng_cbar(st, c, w);
+        if (c.lane == 63) stat[w.cw] = s1;
+        eng_cbar<CF>(st, c, w);
+        eng_stamp(st, c, w, k, 8);
         float tot = 0.f;
-        for (int i = 0; i < ENG_NC; ++i) tot += reinterpret_cast<float*>(c.fx + EF_STAT)[i];
+        for (int i = 0; i < CF::NC; ++i) tot += stat[i];
+        if (na.kind == 2) {
+            mean = tot / (float)K;
+            float s2 = 0.f;
+#pragma unroll
+            for (int i = 0; i < CF::MAXG; ++i)
+                if (64 * (w.cw + CF::NC * i) + c.lane < npairs) s2 += norm_stat2(xv[i], mean);
+            s2 = wave_sum_to_lane63(s2);
+            if (c.lane == 63) stat[16 + w.cw] = s2;
+            eng_cbar<CF>(st, c, w);
+            eng_stamp(st, c, w, k, 9);
+            tot = 0.f;
+            for (int i = 0; i < CF::NC; ++i) tot += stat[16 + i];
+        }
         r = norm_scale(na, tot);
     }
-    const unsigned char* nslot = c.ring;
-    if (na.kind == 1) {  // the norm weights arrived through the ring (one slot, in front of the op's weights)
-        eng_wait_full(st, c, w, w.seq);
-        nslot = c.ring + (w.seq % ENG_NSLOT) * ENG_SLOT_BYTES;
-    }
+    const int nb_off = ((K * 2 + 1023) >> 10) << 10;  // LayerNorm bias behind the weights
+    // once, or twice when a second norm of the same input is asked for (parallel residual: the MLP's norm_2; the row
+    // statistics are the input's, so the up-projection that follows finds its input in the other buffer and gathers nothing)
+    const int nrounds = (na.kind != 0 && op->norm2_w != nullptr) ? 2 : 1;
+    for (int which = 0; which < nrounds; ++which) {
+        const unsigned char* nslot = c.ring;
+        const bool has_nb = na.kind == 2 && (which ? op->norm2_b : op->norm_b) != nullptr;
+        if (na.kind != 0) {  // the norm weights arrived through the ring (one slot, in front of the op's weights)
+            eng_wait_full<CF>(st, c, w, w.seq);
+            nslot = c.ring + (w.seq % CF::NSLOT) * ENG_SLOT_BYTES;
+            eng_stamp(st, c, w, k, 10);
+        }
+        unsigned char* dstb = ((op->buf != 0) != (which != 0)) ? c.buf1 : c.buf0;
+        float* dxs = reinterpret_cast<float*>(c.fx + EF_XS) + (((op->buf != 0) != (which != 0)) ? 128 : 0);
 #pragma unroll
-    for (int i = 0; i < ENG_MAXG; ++i) {
-        const int g = w.cw + ENG_NC * i;
-        if (g < ngr_pad) {
-            uint32_t o = 0;
-            if (g < ngr) {
-                o = xv[i];
-                const int pr = 64 * g + c.lane;
-                if (na.kind == 1) {
-                    const uint32_t nwp = *reinterpret_cast<const uint32_t*>(nslot + min(pr, npairs - 1) * 4);
-                    o = pr < npairs ? norm_apply(o, nwp, 0u, 1, 0.f, r) : 0u;
+        for (int i = 0; i < CF::MAXG; ++i) {
+            const int g = w.cw + CF::NC * i;
+            if (g < ngr_pad) {
+                uint32_t o = 0;
+                if (g < ngr) {
+                    o = xv[i];
+                    const int pr = 64 * g + c.lane;
+                    if (na.kind != 0) {
+                        const uint32_t nwp = *reinterpret_cast<const uint32_t*>(nslot + min(pr, npairs - 1) * 4);
+                        uint32_t nbp = 0u;
+                        if (has_nb) nbp = *reinterpret_cast<const uint32_t*>(nslot + nb_off + min(pr, npairs - 1) * 4);
+                        o = pr < npairs ? norm_apply(o, nwp, nbp, na.kind, mean, r) : 0u;
+                    }
+                }
+                *reinterpret_cast<uint32_t*>(dstb + g * ENG_GROUP_STRIDE + c.lane * 4) = o;
+                if (CF::WF == PARROT_ENG_W_E4) {  // the int4 arithmetic needs the groups' sums
+                    const float t = wave_sum_to_lane63(bflo(o) + bfhi(o));
+                    if (c.lane == 63) dxs[g] = t;
                 }
             }
-            *reinterpret_cast<uint32_t*>(buf + g * ENG_GROUP_STRIDE + c.lane * 4) = o;
-            const float t = wave_sum_to_lane63(bflo(o) + bfhi(o));
-            if (c.lane == 63) xs[g] = t;
+        }
+        eng_stamp(st, c, w, k, 11);
+        if (na.kind != 0) {
+            eng_release<CF>(c, w.seq);
+            w.seq += 1;
         }
     }
-    if (na.kind == 1) {
-        eng_release(c, w.seq);
-        w.seq += 1;
-    }
-    eng_cbar(st, c, w);
+    eng_cbar<CF>(st, c, w);
 }
 
-// ---- one Linear: the CU's blocks, quads dealt round-robin over the consumer waves
+// ---- one Linear: the CU's blocks, units dealt round-robin over the consumer waves
+template <class CF>
 __device__ __forceinline__ void eng_gemv(const EngState& st, const EngCtx& c0, EngCons& w, const EngOp* op, int k) {
+    constexpr int MAXQ = CF::MAXQ, NSLOT = CF::NSLOT;
     eng_stamp(st, c0, w, k, 0);
-    eng_gather(st, c0, w, op, k);
+    if (!op->no_gather) eng_gather<CF>(st, c0, w, op, k);  // (else: the previous Linear's gather left this op's input in its buffer)
     EngCtx c = c0;
     asm volatile("" : "+v"(c.lane));
     if (w.cw == 0 && c.lane == 0) lds_st(c.fx + EF_CUR, (uint32_t)k);
     eng_stamp(st, c, w, k, 1);
-    int b0, b1;
-    eng_block_range(op->nblocks, c.cu, b0, b1);
-    const int nq = op->nq, spb = (nq + 3) >> 2;
+    int bs, nb, bstep;
+    eng_block_range(op->nblocks, c.cu, bs, nb, bstep);
+    constexpr bool e16 = CF::WF == PARROT_ENG_W_E16;
+    const int nq = op->nq, spb = e16 ? nq : (nq + 3) >> 2;
     const unsigned char* buf = op->buf ? c.buf1 : c.buf0;
     const float* xs = reinterpret_cast<const float*>(c.fx + EF_XS) + op->buf * 128;
     float* red = reinterpret_cast<float*>(c.fx + EF_RED);
+    float* redb = reinterpret_cast<float*>(c.fx + EF_REDB);
     float* resid = reinterpret_cast<float*>(c.fx + EF_RESID);
     const int r = c.lane & 7, p = c.lane >> 3;
     const int epi = op->epilogue;
-    const int total = (b1 - b0) * nq;
-    // quads are dealt round-robin over the consumer waves: wave cw takes quads cw, cw + NC, ...; (bl, Q) = (local block,
-    // quad of the row) are stepped without a division per quad
+    const bool has_bias = op->bias != nullptr;
+    const int total = nb * nq;
+    // units are dealt round-robin over the consumer waves: wave cw takes units cw, cw + NC, ...; (bl, Q) = (local block,
+    // unit of the row) are stepped without a division per unit
     int bl = w.cw / nq, Q = w.cw - bl * nq;
-    const int step_b = ENG_NC / nq, step_q = ENG_NC - step_b * nq;
-    for (int idx = w.cw; idx < total; idx += ENG_NC) {
-        const int b = b0 + bl;
-        const int sib = Q >> 2, qq = Q & 3;
-        const int seq = w.seq + bl * spb + sib;
-        eng_wait_full(st, c, w, seq);
-        const unsigned char* slot = c.ring + (seq % ENG_NSLOT) * ENG_SLOT_BYTES;
-        const uint32_t mt = *reinterpret_cast<const uint32_t*>(slot + ENG_META_OFF + (qq * 64 + c.lane) * 4);
-        const int G = 8 * Q + p;
-        const unsigned char* xg = buf + G * ENG_GROUP_STRIDE;
-        const unsigned char* wq = slot + qq * 4096 + c.lane * 16;
-        // one accumulator pair over the quad's four pieces (= the lane's whole quantisation group)
-        float p0 = 0.f, p1 = 0.f;
-        const uint32_t mask = 0x000F000Fu;
-        uint32_t magic = 0x43004300u;
-        asm("" : "+v"(magic));
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const uint4 wv = *reinterpret_cast<const uint4*>(wq + i * 1024);
-            const uint32_t dw[4] = {wv.x, wv.y, wv.z, wv.w};
-#pragma unroll
-            for (int d = 0; d < 4; ++d) {
-                const uint4 xv = *reinterpret_cast<const uint4*>(xg + i * 64 + d * 16);
-                p0 = dot2_bf16(and_or(dw[d], mask, magic), xv.x, p0);
-                p1 = dot2_bf16(and_or(dw[d] >> 4, mask, magic), xv.y, p1);
-                p0 = dot2_bf16(and_or(dw[d] >> 8, mask, magic), xv.z, p0);
-                p1 = dot2_bf16(and_or(dw[d] >> 12, mask, magic), xv.w, p1);
-            }
-        }
-        const float acc = p0 + p1;
-        float v = bflo(mt) * (acc - (128.0f + bfhi(mt)) * xs[G]);
-        v = row8_allsum(v);
+    const int step_b = CF::NC / nq, step_q = CF::NC - step_b * nq;
+    for (int idx = w.cw; idx < total; idx += CF::NC) {
+        const int b = bs + bl * bstep;
         const int rb = (w.bc + bl) % ENG_RED;
-        if (c.lane < 8) red[(rb * ENG_MAXQ + Q) * 8 + c.lane] = v;
+        const int seq = w.seq + bl * spb + (e16 ? Q : (Q >> 2));
+        eng_wait_full<CF>(st, c, w, seq);
+        const unsigned char* slot = c.ring + (seq % NSLOT) * ENG_SLOT_BYTES;
+        float v;
+        if (e16) {
+            // bf16 unit = the slot's 16 pieces: lane (r, p) holds columns 1024 Q + 64 i + 8 p .. + 7 of row r in piece i
+            const unsigned char* wq = slot + c.lane * 16;
+            const unsigned char* xq = buf + (8 * Q) * ENG_GROUP_STRIDE + p * 16;
+            float p0 = 0.f, p1 = 0.f;
+#pragma unroll 1
+            for (int i4 = 0; i4 < 16; i4 += 4) {  // four pieces (32 registers of operands) per round
+#pragma unroll
+                for (int ii = 0; ii < 4; ++ii) {
+                    const int i = i4 + ii;
+                    const uint4 wv = *reinterpret_cast<const uint4*>(wq + i * 1024);
+                    const uint4 xv = *reinterpret_cast<const uint4*>(xq + (i >> 1) * ENG_GROUP_STRIDE + (ii & 1) * 128);
+                    p0 = dot2_bf16(wv.x, xv.x, p0);
+                    p1 = dot2_bf16(wv.y, xv.y, p1);
+                    p0 = dot2_bf16(wv.z, xv.z, p0);
+                    p1 = dot2_bf16(wv.w, xv.w, p1);
+                }
+            }
+            v = p0 + p1;
+            if (Q == 0 && has_bias && c.lane < 8) redb[rb * 8 + c.lane] = bf2f(*reinterpret_cast<const bf16_t*>(slot + ENG_META_OFF + c.lane * 2));
+        } else {
+            const int qq = Q & 3;
+            const uint32_t mt = *reinterpret_cast<const uint32_t*>(slot + ENG_META_OFF + (qq * 64 + c.lane) * 4);
+            const int G = 8 * Q + p;
+            const unsigned char* xg = buf + G * ENG_GROUP_STRIDE;
+            const unsigned char* wq = slot + qq * 4096 + c.lane * 16;
+            // one accumulator pair over the quad's four pieces (= the lane's whole quantisation group)
+            float p0 = 0.f, p1 = 0.f;
+            const uint32_t mask = 0x000F000Fu;
+            uint32_t magic = 0x43004300u;
+            asm("" : "+v"(magic));
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const uint4 wv = *reinterpret_cast<const uint4*>(wq + i * 1024);
+                const uint32_t dw[4] = {wv.x, wv.y, wv.z, wv.w};
+#pragma unroll
+                for (int d = 0; d < 4; ++d) {
+                    const uint4 xv = *reinterpret_cast<const uint4*>(xg + i * 64 + d * 16);
+                    p0 = dot2_bf16(and_or(dw[d], mask, magic), xv.x, p0);
+                    p1 = dot2_bf16(and_or(dw[d] >> 4, mask, magic), xv.y, p1);
+                    p0 = dot2_bf16(and_or(dw[d] >> 8, mask, magic), xv.z, p0);
+                    p1 = dot2_bf16(and_or(dw[d] >> 12, mask, magic), xv.w, p1);
+                }
+            }
+            const float acc = p0 + p1;
+            v = bflo(mt) * (acc - (128.0f + bfhi(mt)) * xs[G]);
+        }
+        v = row8_allsum(v);
+        if (c.lane < 8) red[(rb * MAXQ + Q) * 8 + c.lane] = v;
         lds_drain();  // this wave's reads of the slot have returned, its partial sums are written
         uint32_t t = 0;
         if (c.lane == 0) {
-            lds_add(c.fx + EF_CONS + (seq % ENG_NSLOT) * 4, 1u);
+            lds_add(c.fx + EF_CONS + (seq % NSLOT) * 4, 1u);
             t = lds_add(c.fx + EF_DONE + rb * 4, 1u);
         }
         t = __builtin_amdgcn_readfirstlane(t);
         if ((int)t == nq - 1) {
-            // ---- this wave finished the block's last quad: fixed-order sum, epilogue, publish
+            // ---- this wave finished the block's last unit: fixed-order sum, epilogue, publish
             asm volatile("" ::: "memory");  // the partial sums are read behind the counter, not speculated above it
             lds_st(c.fx + EF_DONE + rb * 4, 0u);
             float a = 0.f;
-            for (int q = 0; q < nq; ++q) a += red[(rb * ENG_MAXQ + q) * 8 + r];
+            for (int q = 0; q < nq; ++q) a += red[(rb * MAXQ + q) * 8 + r];
+            if (has_bias) a += redb[rb * 8 + r];
             float o = rbf(a);
             if (epi == PARROT_EPI_RESIDUAL) {
-                const int lr = bl * 8 + r;  // the CU's own rows: the same blocks in every n_embd-row op
-                const float res = op->res_embedding ? bf2f(((glb_cu16_t)c.emb)[b * 8 + r]) : resid[lr & 63];
+                const int lr = (bl * 8 + r) & 63;  // the CU's own rows: the same blocks in every n_embd-row op
+                const float res = op->res_embedding ? bf2f(((glb_cu16_t)c.emb)[b * 8 + r]) : resid[op->res_in * 64 + lr];
                 o = rbf(res + o);
-                if (c.lane < 8) resid[lr & 63] = o;
+                if (c.lane < 8) resid[op->res_out * 64 + lr] = o;
+            } else if (epi == PARROT_EPI_GELU) {
+                o = gelu_erf(o);
             } else if (epi == PARROT_EPI_SWIGLU) {
                 const float gate = __shfl(o, (c.lane + 4) & 63, 64);  // lanes 0..3: fc_1 rows, 4..7: the same rows of fc_2
                 o = rbf(rbf(silu(o)) * gate);
@@ -646,7 +830,7 @@ __device__ __forceinline__ void eng_gemv(const EngState& st, const EngCtx& c0, E
                         w.best_i = li;
                     }
                 }
-            } else {
+            } else if (op->publish) {
                 const int rows = epi == PARROT_EPI_SWIGLU ? 4 : 8;
                 if (c.lane < rows && (c.lane & 1) == 0)
                     st_gran(reinterpret_cast<uint64_t*>(op->out) + ((b * rows + c.lane) >> 1), ob | (nb << 16), c.epoch);
@@ -659,31 +843,34 @@ __device__ __forceinline__ void eng_gemv(const EngState& st, const EngCtx& c0, E
             ++bl;
         }
     }
-    w.seq += (b1 - b0) * spb;
-    w.bc += b1 - b0;
+    w.seq += nb * spb;
+    w.bc += nb;
     eng_stamp(st, c, w, k, 2);
-    if (st.dbg != nullptr && c.cu == 0 && w.cw == 0 && c.lane == 0) st.dbg[k * 8 + 3] = w.waited | ((uint64_t)w.gate_spins << 40);
+    if ((ENG_STAMPS && st.dbg != nullptr) && c.cu == 0 && w.cw == 0 && c.lane == 0) st.dbg[k * 16 + 3] = w.waited | ((uint64_t)w.gate_spins << 40);
     w.waited = 0;
 }
 
 // ---- attention op: split + RoPE + KV append + softmax(q k^T / sqrt(hs)) v over the CU's key range, partial states to the
 // group's leader CU, which merges them into the heads
-template <int HS, int HQ>
+template <class CF, int HS, int HQ>
 __device__ __forceinline__ void eng_attn(const EngState& st, const EngCtx& c0, EngCons& w, const EngOp* op, int k) {
     constexpr int LPR = HS / 8, KPP = 64 / LPR, PW = HS + 2;
     EngCtx c = c0;
     asm volatile("" : "+v"(c.lane));
     eng_stamp(st, c, w, k, 0);
     const EngKeys ky = eng_keys<HS>(st, c.cu, c.pos);
+    // scratch in activation buffer 0.  Behind the QKV Linear its last readers passed the barriers of that op's gather; behind
+    // a Linear that read buffer 0 itself (parallel residual: the MLP's up-projection runs between QKV and attention) the
+    // waves meet first
+    if (op->buf) eng_cbar<CF>(st, c, w);
     if (!ky.part) {
-        eng_cbar(st, c, w);
+        eng_cbar<CF>(st, c, w);
         return;
     }
-    // scratch in activation buffer 0 (its last readers passed the barriers of this block's QKV gather)
     unsigned char* sc = c.buf0;
     uint32_t* raw = reinterpret_cast<uint32_t*>(sc);                                      // [(HQ + 2) * HS / 2] bf16 pairs
     float* wpart = reinterpret_cast<float*>(sc + (HQ + 2) * HS * 2);                      // [NC][HQ][PW]
-    float* stage = wpart + ENG_NC * HQ * PW;                                              // [HQ][nsplit][PW]
+    float* stage = wpart + CF::NC * HQ * PW;                                              // [HQ][nsplit][PW]
     const float* rope = reinterpret_cast<const float*>(c.fx + EF_ROPE);
     const int dl = c.lane % LPR, j = c.lane / LPR;
     const int n_elem = st.n_elem, half_n = n_elem >> 1;
@@ -699,14 +886,14 @@ __device__ __forceinline__ void eng_attn(const EngState& st, const EngCtx& c0, E
         } else if (w.cw < NLOAD) {
             eng_wait_lds_ge(st, c, EF_GATE, (uint32_t)(k + 1), 0x53000000u | (uint32_t)k);
         }
-        for (int t = w.cw; t < NLOAD; t += ENG_NC) {
+        for (int t = w.cw; t < NLOAD; t += CF::NC) {
             const int pr = 64 * t + c.lane;
             const uint64_t* p = in + min(pr, NPAIR - 1);
             const uint32_t d = eng_gran_wait(st, c, p, ld_gran(p), pr < NPAIR, 0x50000000u | (uint32_t)k);
             if (pr < NPAIR) raw[pr] = d;
         }
     }
-    eng_cbar(st, c, w);
+    eng_cbar<CF>(st, c, w);
     eng_stamp(st, c, w, k, 1);
     if (w.cw == 0 && c.lane == 0) lds_st(c.fx + EF_CUR, (uint32_t)k);
     // this lane's 8 dims of every query head (RoPE, rounded to bf16, scaled), of the new key (RoPE) and the new value.
@@ -775,10 +962,10 @@ __device__ __forceinline__ void eng_attn(const EngState& st, const EngCtx& c0, E
 #pragma unroll
         for (int e = 0; e < 8; ++e) acc[h][e] = 0.f;
     }
-    for (int u = w.cw; u < ky.nunits; u += ENG_NC) {
+    for (int u = w.cw; u < ky.nunits; u += CF::NC) {
         const int seq = w.seq + (u >> 3);
-        eng_wait_full(st, c, w, seq);
-        const unsigned char* slot = c.ring + (seq % ENG_NSLOT) * ENG_SLOT_BYTES + (u & 7) * 2048;
+        eng_wait_full<CF>(st, c, w, seq);
+        const unsigned char* slot = c.ring + (seq % CF::NSLOT) * ENG_SLOT_BYTES + (u & 7) * 2048;
         uint4 kv = *reinterpret_cast<const uint4*>(slot + c.lane * 16);
         uint4 vv = *reinterpret_cast<const uint4*>(slot + 1024 + c.lane * 16);
         const int kidx = ky.kb + u * KPP + j;
@@ -809,7 +996,7 @@ __device__ __forceinline__ void eng_attn(const EngState& st, const EngCtx& c0, E
                 m[h] = mn;
             }
         }
-        eng_release(c, seq);
+        eng_release<CF>(c, seq);
     }
     w.seq += (ky.nunits + 7) >> 3;
     eng_stamp(st, c, w, k, 6);
@@ -830,15 +1017,15 @@ __device__ __forceinline__ void eng_attn(const EngState& st, const EngCtx& c0, E
             wp[HS + 1] = L;
         }
     }
-    eng_cbar(st, c, w);
+    eng_cbar<CF>(st, c, w);
     eng_stamp(st, c, w, k, 7);
     if (w.cw == 0) {
 #pragma unroll
         for (int h = 0; h < HQ; ++h) {
             float M = -INFINITY;
-            for (int t = 0; t < ENG_NC; ++t) M = fmaxf(M, wpart[(t * HQ + h) * PW + HS]);
+            for (int t = 0; t < CF::NC; ++t) M = fmaxf(M, wpart[(t * HQ + h) * PW + HS]);
             float L = 0.f, o0 = 0.f, o1 = 0.f;
-            for (int t = 0; t < ENG_NC; ++t) {
+            for (int t = 0; t < CF::NC; ++t) {
                 const float* wp = wpart + (t * HQ + h) * PW;
                 const float f = (wp[HS] == -INFINITY) ? 0.f : __expf(wp[HS] - M);
                 L += wp[HS + 1] * f;
@@ -863,7 +1050,7 @@ __device__ __forceinline__ void eng_attn(const EngState& st, const EngCtx& c0, E
     if (ky.s == 0) {  // the group's leader CU merges the splits into the heads: every wave fetches a share of the partial states
         const int cnt = HQ * ky.ns * PW;  // the group's heads lie back to back
         const uint64_t* pg = op->part + (int64_t)ky.g * HQ * ky.ns * PW;
-        constexpr int NLD = (2 * 8 * PW + 63) / 64, NPW = (NLD + ENG_NC - 1) / ENG_NC;  // HQ <= 2, nsplit <= 8
+        constexpr int NLD = (2 * 8 * PW + 63) / 64, NPW = (NLD + CF::NC - 1) / CF::NC;  // HQ <= 2, nsplit <= 8
         if (!ENG_ATTN_GATE) {
         } else if (w.cw == 0) {  // one poller per CU
             (void)eng_gran_wait(st, c, pg + (cnt - 1), 0, true, 0x54000000u | (uint32_t)k);
@@ -875,11 +1062,11 @@ __device__ __forceinline__ void eng_attn(const EngState& st, const EngCtx& c0, E
         for (; ky.ns > 1;) {  // flat sweep: every load in flight at once, repeated until every tag matches
             uint64_t gv[NPW];
 #pragma unroll
-            for (int t = 0; t < NPW; ++t) gv[t] = ld_gran(pg + min(64 * (w.cw + ENG_NC * t) + c.lane, cnt - 1));
+            for (int t = 0; t < NPW; ++t) gv[t] = ld_gran(pg + min(64 * (w.cw + CF::NC * t) + c.lane, cnt - 1));
             bool ok = true;
 #pragma unroll
             for (int t = 0; t < NPW; ++t) {
-                const int i = 64 * (w.cw + ENG_NC * t) + c.lane;
+                const int i = 64 * (w.cw + CF::NC * t) + c.lane;
                 ok = ok && ((uint32_t)(gv[t] >> 32) == c.epoch || i >= cnt);
                 if (i < cnt) stage[i] = __uint_as_float((uint32_t)gv[t]);
             }
@@ -893,7 +1080,7 @@ __device__ __forceinline__ void eng_attn(const EngState& st, const EngCtx& c0, E
                 }
             }
         }
-        eng_cbar(st, c, w);
+        eng_cbar<CF>(st, c, w);
         if (w.cw < HQ) {  // one wave per head
             const int h = w.cw;
             const float* sg = stage + h * ky.ns * PW;
@@ -913,15 +1100,16 @@ __device__ __forceinline__ void eng_attn(const EngState& st, const EngCtx& c0, E
                 st_gran(reinterpret_cast<uint64_t*>(op->out) + (((int64_t)(ky.g * HQ + h) * HS) >> 1) + c.lane, pk, c.epoch);
         }
     }
-    eng_cbar(st, c, w);  // the scratch is free again (the next op's input goes into this buffer)
+    eng_cbar<CF>(st, c, w);  // the scratch is free again (the next op's input goes into this buffer)
     eng_stamp(st, c, w, k, 2);
-    if (st.dbg != nullptr && c.cu == 0 && w.cw == 0 && c.lane == 0) st.dbg[k * 8 + 3] = w.waited;
+    if ((ENG_STAMPS && st.dbg != nullptr) && c.cu == 0 && w.cw == 0 && c.lane == 0) st.dbg[k * 16 + 3] = w.waited;
     w.waited = 0;
 }
 
-template <int HS, int HQ>
+template <class CF, int HS, int HQ>
 __device__ __forceinline__ void eng_consumer(const EngState& st, const EngCtx& c, int cw) {
     EngCons w;
+    if (CF::SPIN == 1) __builtin_amdgcn_s_setprio(1);
     w.cw = cw;
     w.cb_gen = 0;
     w.seq = 0;
@@ -934,9 +1122,9 @@ __device__ __forceinline__ void eng_consumer(const EngState& st, const EngCtx& c
         const EngOp opv = eng_fetch_op(st.ops, k);
         const EngOp* op = &opv;
         if (op->type == PARROT_ENG_GEMV)
-            eng_gemv(st, c, w, op, k);
+            eng_gemv<CF>(st, c, w, op, k);
         else
-            eng_attn<HS, HQ>(st, c, w, op, k);
+            eng_attn<CF, HS, HQ>(st, c, w, op, k);
     }
     if (!st.greedy) {
         if (c.cu == 0 && cw == 0 && c.lane == 0) st.epoch[0] = c.epoch + 1;
@@ -958,11 +1146,11 @@ __device__ __forceinline__ void eng_consumer(const EngState& st, const EngCtx& c
         reinterpret_cast<float*>(c.fx + EF_BESTV)[cw] = bv;
         reinterpret_cast<int*>(c.fx + EF_BESTI)[cw] = bi;
     }
-    eng_cbar(st, c, w);
+    eng_cbar<CF>(st, c, w);
     if (cw != 0) return;
     bv = -INFINITY;
     bi = 0x7fffffff;
-    for (int t = 0; t < ENG_NC; ++t) {
+    for (int t = 0; t < CF::NC; ++t) {
         const float ov = reinterpret_cast<float*>(c.fx + EF_BESTV)[t];
         const int oi = reinterpret_cast<int*>(c.fx + EF_BESTI)[t];
         if (oi != 0x7fffffff && (bi == 0x7fffffff || ov > bv || (ov == bv && oi < bi))) {
@@ -1004,13 +1192,14 @@ __device__ __forceinline__ void eng_consumer(const EngState& st, const EngCtx& c
     }
 }
 
-template <int HS, int HQ>
+template <int HS, int HQ, int BIG, int WFMT>
 __global__ void __launch_bounds__(ENG_THREADS)
 eng_token_kernel(EngState st) {
+    typedef EngCfg<BIG, WFMT> CF;
     extern __shared__ __attribute__((aligned(16))) unsigned char eng_smem[];
     EngCtx c;
     c.ring = eng_smem;
-    c.buf0 = eng_smem + ENG_NSLOT * ENG_SLOT_BYTES;
+    c.buf0 = eng_smem + CF::NSLOT * ENG_SLOT_BYTES;
     c.buf1 = c.buf0 + st.lds_buf0_bytes;
     c.fx = c.buf1 + st.lds_buf1_bytes;
     c.epoch = st.epoch[0];
@@ -1021,7 +1210,7 @@ eng_token_kernel(EngState st) {
     if (tok < 0 || tok >= st.V) tok = 0;
     c.emb = reinterpret_cast<const bf16_t*>(st.wte) + tok * st.d;
     // control words and the RoPE row of this position
-    for (int i = threadIdx.x; i < (EF_BYTES - EF_STAT) / 4; i += ENG_THREADS) reinterpret_cast<uint32_t*>(c.fx + EF_STAT)[i] = 0u;
+    for (int i = threadIdx.x; i < (EF_RED - EF_STAT) / 4; i += ENG_THREADS) reinterpret_cast<uint32_t*>(c.fx + EF_STAT)[i] = 0u;
     if ((int)threadIdx.x < 2 * st.n_elem) {
         const int which = threadIdx.x / st.n_elem, d = threadIdx.x % st.n_elem;
         const __half* tab = reinterpret_cast<const __half*>(which ? st.rope_sin : st.rope_cos);
@@ -1029,10 +1218,10 @@ eng_token_kernel(EngState st) {
     }
     __syncthreads();
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    if (wave == 0)
-        eng_loader<HS>(st, c);
+    if (wave < CF::NLOAD)
+        eng_loader<CF, HS>(st, c, wave);
     else
-        eng_consumer<HS, HQ>(st, c, wave - 1);
+        eng_consumer<CF, HS, HQ>(st, c, wave - CF::NLOAD);
 }
 
 // ------------------------------------------------------------------------------------------ E4 repack
@@ -1088,12 +1277,32 @@ e4_repack_kernel(const uint8_t* __restrict__ q1, const bf16_t* __restrict__ s1, 
     e4[tid] = make_uint4(dw[0], dw[1], dw[2], dw[3]);
 }
 
+// ------------------------------------------------------------------------------------------ E16 repack
+// bf16 weights: per 8 rows (a block) and 1024 columns (a unit = one ring slot) 16 pieces of 1 KiB; in piece i lane l holds
+// the 8 columns 1024 Q + 64 i + 8 (l / 8) .. + 7 of row l % 8.  One thread per 16-byte unit of the image.
+__global__ void __launch_bounds__(256)
+e16_repack_kernel(const bf16_t* __restrict__ w1, const bf16_t* __restrict__ w2, int N, int K, int nblocks, int nq, uint4* __restrict__ e16) {
+    const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (tid >= (int64_t)nblocks * nq * 1024) return;
+    const int ln = (int)(tid & 63), i = (int)((tid >> 6) & 15);
+    const int64_t bq = tid >> 10;
+    const int B = (int)(bq / nq), Q = (int)(bq % nq);
+    const int r = ln & 7, p = ln >> 3;
+    const bool dual = w2 != nullptr;
+    const bf16_t* w = (dual && r >= 4) ? w2 : w1;
+    const int row = dual ? B * 4 + (r & 3) : B * 8 + r;
+    const int k0 = 1024 * Q + 64 * i + 8 * p;
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (k0 < K) v = *reinterpret_cast<const uint4*>(w + (int64_t)row * K + k0);
+    e16[tid] = v;
+}
+
 static int e4_shape(int N, int K, int dual, int* nblocks, int* nq) {
     PARROT_REQUIRE(N > 0 && K > 0, "e4: N and K must be positive (N=%d K=%d)", N, K);
     PARROT_UNSUPPORTED(K % 32 == 0, "e4: K=%d must be a multiple of 32", K);
     PARROT_UNSUPPORTED(N % (dual ? 4 : 8) == 0, "e4: N=%d must be a multiple of %d", N, dual ? 4 : 8);
     *nq = (K + 1023) / 1024;
-    PARROT_UNSUPPORTED(*nq <= ENG_MAXQ, "e4: K=%d is beyond the %d columns the stream engine is built for", K, ENG_MAXQ * 1024);
+    PARROT_UNSUPPORTED(*nq <= ENG_MAXQ_BIG, "e4: K=%d is beyond the %d columns the stream engine is built for", K, ENG_MAXQ_BIG * 1024);
     *nblocks = dual ? N / 4 : N / 8;
     return PARROT_OK;
 }
@@ -1101,6 +1310,7 @@ static int e4_shape(int N, int K, int dual, int* nblocks, int* nq) {
 static int64_t eng_attn_scratch_bytes(int hs, int hq, int nsplit) {
     return (int64_t)(hq + 2) * hs * 2 + (int64_t)(ENG_NC + nsplit) * hq * (hs + 2) * 4;
 }
+static bool eng_is_big(int kmax) { return kmax > ENG_MAXQ_STD * 1024; }
 
 }  // namespace parrot
 
@@ -1131,16 +1341,47 @@ int parrot_e4_repack(const void* q1, const void* s1, const void* z1, const void*
                   (uint4*)e4);
 }
 
+int64_t parrot_e16_bytes(int N, int K, int dual) {
+    int nblocks, nq;
+    const int rc = e4_shape(N, K, dual, &nblocks, &nq);  // the same block / unit grid as E4
+    if (rc != PARROT_OK) return rc;
+    return (int64_t)nblocks * nq * 16384;
+}
+
+int parrot_e16_repack(const void* w1, const void* w2, int N, int K, void* e16, void* stream) {
+    PARROT_REQUIRE(w1 && e16, "e16_repack: null pointer");
+    PARROT_REQUIRE(aligned16(e16) && aligned16(w1) && (w2 == nullptr || aligned16(w2)), "e16_repack: buffers must be 16-byte aligned");
+    int nblocks, nq;
+    const int rc = e4_shape(N, K, w2 != nullptr, &nblocks, &nq);
+    if (rc != PARROT_OK) return rc;
+    const int64_t blocks = ((int64_t)nblocks * nq * 1024 + 255) / 256;
+    PARROT_UNSUPPORTED(blocks < (1ll << 31), "e16_repack: matrix too large");
+    return launch(K_E4_REPACK, e16_repack_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)w1,
+                  (const bf16_t*)w2, N, K, nblocks, nq, (uint4*)e16);
+}
+
 int64_t parrot_eng_lds_bytes(int K, int hs, int q_per_kv, int nsplit) {
     PARROT_REQUIRE(K > 0, "eng_lds_bytes: K must be positive");
     const int nq = (K + 1023) / 1024;
-    PARROT_UNSUPPORTED(nq <= ENG_MAXQ && nq * 8 <= ENG_NC * ENG_MAXG, "stream engine: K=%d is beyond what it is built for", K);
+    PARROT_UNSUPPORTED(nq <= ENG_MAXQ_BIG && nq * 8 <= ENG_NC * ENG_MAXG_BIG, "stream engine: K=%d is beyond what it is built for", K);
     int64_t b = (int64_t)nq * 8 * ENG_GROUP_STRIDE;
     if (hs > 0) {
         const int64_t a = eng_attn_scratch_bytes(hs, q_per_kv, nsplit);
         if (a > b) b = a;
     }
     return (b + 15) / 16 * 16;
+}
+
+int64_t parrot_eng_lds_total(int kmax, int wfmt, int buf0_bytes, int buf1_bytes) {
+    PARROT_REQUIRE(kmax > 0 && buf0_bytes > 0 && buf1_bytes > 0, "eng_lds_total: sizes must be positive");
+    PARROT_REQUIRE(wfmt == PARROT_ENG_W_E4 || wfmt == PARROT_ENG_W_E16, "eng_lds_total: unknown weight format %d", wfmt);
+    const bool big = eng_is_big(kmax);
+    const int nslot = wfmt == PARROT_ENG_W_E16 ? (big ? EngCfg<1, PARROT_ENG_W_E16>::NSLOT : EngCfg<0, PARROT_ENG_W_E16>::NSLOT)
+                                               : (big ? ENG_NSLOT_BIG : ENG_NSLOT_STD);
+    const int64_t lds = (int64_t)nslot * ENG_SLOT_BYTES + buf0_bytes + buf1_bytes +
+                        (big ? EF_RED + ENG_RED * ENG_MAXQ_BIG * 32 : EF_RED + ENG_RED * ENG_MAXQ_STD * 32);
+    PARROT_UNSUPPORTED(lds <= 160 * 1024, "stream engine: needs %lld B of LDS", (long long)lds);
+    return lds;
 }
 
 int parrot_eng_step(const parrot_eng_state_t* state_host, void* stream) {
@@ -1157,26 +1398,45 @@ int parrot_eng_step(const parrot_eng_state_t* state_host, void* stream) {
     PARROT_REQUIRE(st.lds_buf0_bytes > 0 && st.lds_buf0_bytes % 16 == 0 && st.lds_buf1_bytes > 0 && st.lds_buf1_bytes % 16 == 0,
                    "eng_step: LDS buffer sizes must be positive multiples of 16");
     PARROT_REQUIRE(st.lds_buf0_bytes >= eng_attn_scratch_bytes(st.hs, st.q_per_kv, st.nsplit), "eng_step: LDS buffer 0 smaller than the attention scratch");
-    const size_t lds = (size_t)ENG_NSLOT * ENG_SLOT_BYTES + st.lds_buf0_bytes + st.lds_buf1_bytes + EF_BYTES;
-    PARROT_UNSUPPORTED(lds <= 160 * 1024, "stream engine: needs %zu B of LDS", lds);
+    PARROT_REQUIRE(st.kmax >= 1, "eng_step: kmax (the largest input of any op) must be set");
+    {
+        const int nqm = (st.kmax + 1023) / 1024;
+        PARROT_UNSUPPORTED(nqm <= ENG_MAXQ_BIG, "stream engine: K=%d is beyond what it is built for", st.kmax);
+        PARROT_REQUIRE(st.lds_buf0_bytes >= (int64_t)nqm * 8 * ENG_GROUP_STRIDE || st.lds_buf1_bytes >= (int64_t)nqm * 8 * ENG_GROUP_STRIDE,
+                       "eng_step: no LDS buffer holds an input of kmax=%d elements", st.kmax);
+    }
+    const int64_t lds_total = parrot_eng_lds_total(st.kmax, st.wfmt, st.lds_buf0_bytes, st.lds_buf1_bytes);
+    if (lds_total < 0) return (int)lds_total;
+    const size_t lds = (size_t)lds_total;
+    const bool big = eng_is_big(st.kmax);
+    PARROT_REQUIRE(st.wfmt == PARROT_ENG_W_E4 || st.wfmt == PARROT_ENG_W_E16, "eng_step: unknown weight format %d", st.wfmt);
+    const bool e16 = st.wfmt == PARROT_ENG_W_E16;
     hipStream_t s = (hipStream_t)stream;
-#define PARROT_ENG_GO(HSV, HQV)                                                                                          \
+#define PARROT_ENG_GO(HSV, HQV, BIGV, WFV)                                                                               \
     do {                                                                                                                 \
         static bool attr_set = false;                                                                                    \
         if (!attr_set) {                                                                                                 \
-            hipError_t e = hipFuncSetAttribute((const void*)eng_token_kernel<HSV, HQV>,                                  \
+            hipError_t e = hipFuncSetAttribute((const void*)eng_token_kernel<HSV, HQV, BIGV, WFV>,                       \
                                                hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);                 \
             if (e != hipSuccess) return hip_fail(e, "hipFuncSetAttribute");                                               \
             attr_set = true;                                                                                             \
         }                                                                                                                \
-        return launch(K_ENG_TOKEN, eng_token_kernel<HSV, HQV>, dim3(ENG_WGS), dim3(ENG_THREADS), lds, s, st);            \
+        return launch(K_ENG_TOKEN, eng_token_kernel<HSV, HQV, BIGV, WFV>, dim3(ENG_WGS), dim3(ENG_THREADS), lds, s, st); \
+    } while (0)
+#define PARROT_ENG_GO2(HSV, HQV)                                      \
+    do {                                                              \
+        if (e16 && big) PARROT_ENG_GO(HSV, HQV, 1, PARROT_ENG_W_E16); \
+        if (e16) PARROT_ENG_GO(HSV, HQV, 0, PARROT_ENG_W_E16);        \
+        if (big) PARROT_ENG_GO(HSV, HQV, 1, PARROT_ENG_W_E4);         \
+        PARROT_ENG_GO(HSV, HQV, 0, PARROT_ENG_W_E4);                  \
     } while (0)
     if (st.hs == 128) {
-        if (st.q_per_kv == 1) PARROT_ENG_GO(128, 1);
-        PARROT_ENG_GO(128, 2);
+        if (st.q_per_kv == 1) PARROT_ENG_GO2(128, 1);
+        PARROT_ENG_GO2(128, 2);
     }
-    if (st.q_per_kv == 1) PARROT_ENG_GO(64, 1);
-    PARROT_ENG_GO(64, 2);
+    if (st.q_per_kv == 1) PARROT_ENG_GO2(64, 1);
+    PARROT_ENG_GO2(64, 2);
+#undef PARROT_ENG_GO2
 #undef PARROT_ENG_GO
 }
 

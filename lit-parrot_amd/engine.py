@@ -12,8 +12,8 @@ from typing import List, Optional
 import torch
 
 from . import _hip, ops
-from ._hip import (ENG_ATTN, ENG_EPI_LOGITS, ENG_GEMV, ENG_WGS, EPI_NONE, EPI_RESIDUAL, EPI_SWIGLU, EngOp, EngState,
-                   ParrotHipError, check, ptr)
+from ._hip import (ENG_ATTN, ENG_EPI_LOGITS, ENG_GEMV, ENG_W_E4, ENG_W_E16, ENG_WGS, EPI_GELU, EPI_NONE, EPI_RESIDUAL,
+                   EPI_SWIGLU, EngOp, EngState, ParrotHipError, check, ptr)
 from .quantize.gptq import ColBlockQuantizedLinear
 from .rmsnorm import RMSNorm
 
@@ -43,6 +43,26 @@ def e4_image(lin: ColBlockQuantizedLinear, partner: Optional[ColBlockQuantizedLi
     return out
 
 
+def e16_image(lin: torch.nn.Linear, partner: Optional[torch.nn.Linear] = None) -> torch.Tensor:
+    """E16 copy of a bf16 ``nn.Linear`` weight (of the SwiGLU pair): per 8 rows and 1024 columns one 16-KiB ring slot."""
+    lib = _hip.load()
+    N, K = lin.out_features, lin.in_features
+    nbytes = lib.parrot_e16_bytes(N, K, int(partner is not None))
+    if nbytes < 0:
+        raise ParrotHipError(f"parrot_e16_bytes failed ({nbytes}): {_hip.last_error()}")
+    w1 = lin.weight.data.contiguous()
+    w2 = partner.weight.data.contiguous() if partner is not None else None
+    if w1.dtype != torch.bfloat16 or (w2 is not None and w2.dtype != torch.bfloat16):
+        raise ParrotHipError("e16_image: the weights must be bf16")
+    out = torch.empty((nbytes,), dtype=torch.uint8, device=w1.device)
+    check(lib.parrot_e16_repack(ptr(w1), ptr(w2) if w2 is not None else None, N, K, ptr(out), _hip.stream()), "parrot_e16_repack")
+    return out
+
+
+def _is_bf16_linear(m) -> bool:
+    return type(m) is torch.nn.Linear and m.weight.dtype == torch.bfloat16
+
+
 class StreamEngine:
     """One-launch-per-token executor bound to a model's weights, KV caches and the loop state of a DecodeSession."""
 
@@ -51,30 +71,52 @@ class StreamEngine:
         """None if the model can run on the engine, else the reason."""
         c = model.config
         linears = [m for m in model.modules() if isinstance(m, torch.nn.Linear) or hasattr(m, "hip_linear")]
-        if not linears or not all(isinstance(m, ColBlockQuantizedLinear) for m in linears):
-            return "not every Linear is an int4 ColBlockQuantizedLinear"
-        if any(m.tile_cols != 128 or m.bias is not None for m in linears):
-            return "int4 group size other than 128, or a bias"
-        if c.parallel_residual or c._norm_class != "RMSNorm" or c._mlp_class != "LLaMAMLP":
-            return "not a sequential-residual RMSNorm / SwiGLU model"
+        if not linears:
+            return "no Linear layers"
+        if all(isinstance(m, ColBlockQuantizedLinear) for m in linears):
+            if any(m.tile_cols != 128 or m.bias is not None for m in linears):
+                return "int4 group size other than 128, or an int4 Linear with a bias"
+        elif not all(_is_bf16_linear(m) for m in linears):
+            return "the Linears are neither all int4 GPTQ nor all plain bf16"
+        norms = [model.transformer.ln_f] + [n for b in model.transformer.h for n in (b.norm_1, getattr(b, "norm_2", None)) if n is not None]
+        for n in norms:
+            if isinstance(n, RMSNorm):
+                if c.n_embd > 8192:
+                    return "norm weights beyond one ring slot"
+            elif isinstance(n, torch.nn.LayerNorm):
+                if c.n_embd > (4096 if n.bias is not None else 8192):
+                    return "norm weights and bias beyond one ring slot"
+            else:
+                return f"unsupported norm {type(n).__name__}"
+        if not c.parallel_residual and c.shared_attention_norm:
+            return "sequential residual with a shared attention norm"
         if c.head_size not in (64, 128) or c.q_per_kv not in (1, 2):
             return f"head size {c.head_size} / q_per_kv {c.q_per_kv}"
         if c.n_query_groups > ENG_WGS or c.rope_n_elem % 16 or c.rope_n_elem > 128:
             return "query group count / rotary width"
-        if c.n_embd % 8 or c.qkv_size % 8 or c.padded_vocab_size % 8 or c.intermediate_size % 4 or c.n_embd > 16384:
+        swiglu = c._mlp_class == "LLaMAMLP"
+        if c.n_embd % 8 or c.qkv_size % 8 or c.padded_vocab_size % 8 or c.intermediate_size % (4 if swiglu else 8) or c.n_embd > 16384:
             return "row counts that do not fill the 8-row blocks"
         dev = next(model.parameters()).device
         if dev.type != "cuda" or torch.cuda.get_device_properties(dev).multi_processor_count < ENG_WGS:
             return f"the engine keeps {ENG_WGS} workgroups resident, one per CU: the device has fewer CUs"
         lib = _hip.load()
         nsplit = min(8, ENG_WGS // c.n_query_groups)
-        b0 = lib.parrot_eng_lds_bytes(max(c.intermediate_size, c.n_embd), c.head_size, c.q_per_kv, nsplit)
+        kmax = max(c.intermediate_size, c.n_embd)
+        b0 = lib.parrot_eng_lds_bytes(kmax, c.head_size, c.q_per_kv, nsplit)
         b1 = lib.parrot_eng_lds_bytes(c.n_embd, 0, 0, 0)
-        if b0 < 0 or b1 < 0:
+        wfmt = ENG_W_E4 if isinstance(linears[0], ColBlockQuantizedLinear) else ENG_W_E16
+        if b0 < 0 or b1 < 0 or lib.parrot_eng_lds_total(kmax, wfmt, b0, b1) < 0:
             return _hip.last_error()
-        if 7 * 17 * 1024 + b0 + b1 + 8500 > 160 * 1024:
-            return "activation vectors do not fit the LDS beside the weight ring"
         return None
+
+    @staticmethod
+    def faster_than_multi_launch(model, window: int, int4_min_window: int) -> bool:
+        """The measured choice between the two executors: bf16 weights - the engine at every window; int4 -
+        from ``int4_min_window`` KV slots on."""
+        if any(_is_bf16_linear(m) for m in model.modules()):
+            return True
+        return window >= int4_min_window
 
     def __init__(self, model, tokens: torch.Tensor, pos: torch.Tensor, caches: List[tuple], S: int, greedy: bool) -> None:
         why = self.supported(model)
@@ -85,9 +127,11 @@ class StreamEngine:
         dev = tokens.device
         L, d, hs, inter, V = c.n_layer, c.n_embd, c.head_size, c.intermediate_size, c.padded_vocab_size
         nsplit = min(8, ENG_WGS // c.n_query_groups)
+        swiglu = c._mlp_class == "LLaMAMLP"
         self.logits = torch.zeros((1, V), dtype=torch.bfloat16, device=dev)
         # granule buffers, per layer (written once per launch each): qkv, attention partials, heads, x after the
-        # attention branch, MLP hidden, x after the MLP branch; zero = "never written" (the epoch starts at 1)
+        # attention branch (sequential residual only), MLP hidden, x after the block; zero = "never written" (the epoch
+        # starts at 1)
         sizes = dict(qkv=c.qkv_size // 2, part=c.n_head * nsplit * (hs + 2), y=d // 2, xa=d // 2, h=inter // 2, xb=d // 2)
         per_layer = sum(sizes.values())
         self.granules = torch.zeros((L * per_layer + 2 * ENG_WGS,), dtype=torch.int64, device=dev)
@@ -100,39 +144,70 @@ class StreamEngine:
                 off += n
             raise KeyError(name)
 
-        self.e4 = []  # keeps the E4 images alive
-
-        def image(lin, partner=None) -> int:
-            t = e4_image(lin, partner)
-            self.e4.append(t)
-            return t.data_ptr()
-
+        self.images = []  # keeps the E4 / E16 images alive
         ops_list: List[EngOp] = []
 
-        def gemv(W: int, K: int, nblocks: int, epilogue: int, buf: int, inp: Optional[int], out: int, *, norm=None,
-                 in_emb=False, res_emb=False) -> None:
+        def gemv(lin, nblocks: int, epilogue: int, buf: int, inp: Optional[int], out: Optional[int], *, partner=None, norm=None,
+                 norm2=None, no_gather=False, in_emb=False, res_emb=False, res_in=0, res_out=0, publish=True) -> None:
             op = EngOp()
+            K = lin.in_features
             op.type, op.epilogue, op.K, op.nblocks, op.nq, op.buf = ENG_GEMV, epilogue, K, nblocks, (K + 1023) // 1024, buf
-            op.W, op.inp, op.out = W, inp, out
+            if isinstance(lin, ColBlockQuantizedLinear):
+                img, op.wfmt = e4_image(lin, partner), ENG_W_E4
+            else:
+                img, op.wfmt = e16_image(lin, partner), ENG_W_E16
+                if lin.bias is not None:
+                    if partner is not None:
+                        raise ParrotHipError("stream engine: a SwiGLU pair with biases is not built")
+                    op.bias = ptr(lin.bias.data)
+            self.images.append(img)
+            op.W, op.inp, op.out = img.data_ptr(), inp, out
             if norm is not None:
-                if not isinstance(norm, RMSNorm):
-                    raise ParrotHipError(f"stream engine: unsupported norm {type(norm).__name__}")
-                op.norm_kind, op.norm_w, op.norm_eps = 1, ptr(norm.weight.data), float(norm.eps)
-            op.in_embedding, op.res_embedding = int(in_emb), int(res_emb)
+                op.norm_w, op.norm_eps = ptr(norm.weight.data), float(norm.eps)
+                if isinstance(norm, RMSNorm):
+                    op.norm_kind = 1
+                else:
+                    op.norm_kind = 2
+                    if norm.bias is not None:
+                        op.norm_b = ptr(norm.bias.data)
+            if norm2 is not None:  # a second norm of the same input, for the next op (which then gathers nothing)
+                if type(norm2) is not type(norm) or float(norm2.eps) != float(norm.eps):
+                    raise ParrotHipError("stream engine: the two norms of a parallel-residual block must be of one kind")
+                op.norm2_w = ptr(norm2.weight.data)
+                if getattr(norm2, "bias", None) is not None:
+                    op.norm2_b = ptr(norm2.bias.data)
+            op.in_embedding, op.res_embedding, op.no_gather = int(in_emb), int(res_emb), int(no_gather)
+            op.res_in, op.res_out, op.publish = res_in, res_out, int(publish)
             ops_list.append(op)
 
         for i, (block, (kc, vc)) in enumerate(zip(model.transformer.h, caches)):
             first = i == 0
-            gemv(image(block.attn.attn), d, c.qkv_size // 8, EPI_NONE, 1, None if first else gran(i - 1, "xb"), gran(i, "qkv"),
-                 norm=block.norm_1, in_emb=first)
+            x_in = None if first else gran(i - 1, "xb")
+            mlp_norm = (block.norm_1 if c.shared_attention_norm else block.norm_2) if c.parallel_residual else None
+            gemv(block.attn.attn, c.qkv_size // 8, EPI_NONE, 1, x_in, gran(i, "qkv"), norm=block.norm_1, norm2=mlp_norm, in_emb=first)
             at = EngOp()
             at.type, at.inp, at.out, at.part = ENG_ATTN, gran(i, "qkv"), gran(i, "y"), gran(i, "part")
             at.k_cache, at.v_cache = ptr(kc), ptr(vc)
-            ops_list.append(at)
-            gemv(image(block.attn.proj), d, d // 8, EPI_RESIDUAL, 0, gran(i, "y"), gran(i, "xa"), res_emb=first)
-            gemv(image(block.mlp.fc_1, block.mlp.fc_2), d, inter // 4, EPI_SWIGLU, 1, gran(i, "xa"), gran(i, "h"), norm=block.norm_2)
-            gemv(image(block.mlp.proj), inter, d // 8, EPI_RESIDUAL, 0, gran(i, "h"), gran(i, "xb"))
-        gemv(image(model.lm_head), d, V // 8, ENG_EPI_LOGITS, 1, gran(L - 1, "xb"), ptr(self.logits), norm=model.transformer.ln_f)
+            mlp = block.mlp
+            up, partner = (mlp.fc_1, mlp.fc_2) if swiglu else (mlp.fc, None)
+            up_blocks, up_epi = (inter // 4, EPI_SWIGLU) if swiglu else (inter // 8, EPI_GELU)
+            if c.parallel_residual:
+                # x + attn(norm_1(x)) + mlp(norm_2(x)) (model.py:166-171).  Both norms see the block's input: the QKV op's
+                # gather applies both (same row statistics) and leaves norm_2(x) in the other LDS buffer, so the MLP's
+                # up-projection starts without a gather and runs between QKV and attention - by the time its weights
+                # have streamed the QKV vector has long arrived everywhere.  The out-projection keeps x + attn in the CU
+                # that owns the rows, the down-projection adds its rows and hands the block's output over.
+                gemv(up, up_blocks, up_epi, 0, None, gran(i, "h"), partner=partner, no_gather=True)
+                at.buf = 1  # the up-projection's input sits in buffer 0, the attention scratch
+                ops_list.append(at)
+                gemv(block.attn.proj, d // 8, EPI_RESIDUAL, 1, gran(i, "y"), None, res_emb=first, res_in=0, res_out=1, publish=False)
+                gemv(mlp.proj, d // 8, EPI_RESIDUAL, 0, gran(i, "h"), gran(i, "xb"), res_in=1, res_out=0)
+            else:
+                ops_list.append(at)
+                gemv(block.attn.proj, d // 8, EPI_RESIDUAL, 0, gran(i, "y"), gran(i, "xa"), res_emb=first)
+                gemv(up, up_blocks, up_epi, 1, gran(i, "xa"), gran(i, "h"), partner=partner, norm=block.norm_2)
+                gemv(mlp.proj, d // 8, EPI_RESIDUAL, 0, gran(i, "h"), gran(i, "xb"))
+        gemv(model.lm_head, V // 8, ENG_EPI_LOGITS, 1, gran(L - 1, "xb"), ptr(self.logits), norm=model.transformer.ln_f)
 
         arr = (EngOp * len(ops_list))(*ops_list)
         self.ops_dev = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(dev)
@@ -147,7 +222,9 @@ class StreamEngine:
         st.rope_cos, st.rope_sin = ptr(cos), ptr(sin)
         st.n_elem, st.n_groups, st.q_per_kv, st.hs, st.S = c.rope_n_elem, c.n_query_groups, c.q_per_kv, hs, S
         st.V, st.rsqrt_mode, st.nsplit, st.greedy = V, ops.RMSNORM_RSQRT_MODE, nsplit, int(greedy)
-        st.lds_buf0_bytes = self.lib.parrot_eng_lds_bytes(max(inter, d), hs, c.q_per_kv, nsplit)
+        st.kmax = max(inter, d)
+        st.wfmt = ops_list[0].wfmt
+        st.lds_buf0_bytes = self.lib.parrot_eng_lds_bytes(st.kmax, hs, c.q_per_kv, nsplit)
         st.lds_buf1_bytes = self.lib.parrot_eng_lds_bytes(d, 0, 0, 0)
         st.arg = self.granules.data_ptr() + 8 * L * per_layer
         self.state = st
@@ -157,7 +234,7 @@ class StreamEngine:
 
     def enable_stamps(self) -> torch.Tensor:
         """Diagnostic: let workgroup 0 record 100 MHz timestamps per op (enter, input ready, last unit done)."""
-        self.dbg = torch.zeros((self.n_ops * 8,), dtype=torch.int64, device=self.logits.device)
+        self.dbg = torch.zeros((self.n_ops * 16,), dtype=torch.int64, device=self.logits.device)
         self.state.dbg = ptr(self.dbg)
         self.dbg_all = torch.zeros((self.n_ops * ENG_WGS * 2,), dtype=torch.int64, device=self.logits.device)
         self.state.dbg_all = ptr(self.dbg_all)

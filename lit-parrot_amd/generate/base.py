@@ -53,7 +53,7 @@ class DecodeSession:
         if engine is None:
             engine = ENGINE_DEFAULT
         if engine == "auto":
-            engine = max_seq_length >= ENGINE_AUTO_MIN_WINDOW
+            engine = StreamEngine.faster_than_multi_launch(model, max_seq_length, ENGINE_AUTO_MIN_WINDOW)
         if engine and StreamEngine.supported(model) is None:
             self.eng = StreamEngine(model, self.tokens, self.pos, self.caches, max_seq_length, greedy)
 
@@ -113,7 +113,9 @@ class DecodeSession:
 
 # The one-launch stream engine (engine.py) for the models it is built for (Llama-2 7B family, int4 g128).  Measured on
 # Llama-2-7B int4: its token time barely moves with the context (K/V rows stream through the same LDS ring
-# as the weights, on all 256 CUs), the multi-launch step's grows; they cross below 1k keys.  "auto" picks by window size.
+# as the weights, on all 256 CUs), the multi-launch step's grows; they cross below 1k keys.  With bf16 weights (two loader
+# waves, a parallel-residual block with three hand-offs instead of five) it is ahead at every window: StableLM-3B 752 vs
+# 654 tokens/s behind a 512-token prompt.  "auto" picks by weight format and window size.
 ENGINE_DEFAULT = "auto"
 ENGINE_AUTO_MIN_WINDOW = 1024
 

@@ -47,7 +47,14 @@ def test_argument_validation_needs_no_gpu(hip_lib):
     assert hip_lib.parrot_e4_bytes(11008, 4096, 1) == (11008 // 4) * 17 * 1024  # SwiGLU pair: 4 + 4 rows per block
     assert hip_lib.parrot_e4_bytes(4096, 11008, 0) == 512 * (44 + 3) * 1024  # 11 quads in 3 slots
     assert hip_lib.parrot_e4_bytes(4096, 4100, 0) == -3 and hip_lib.parrot_e4_bytes(4095, 4096, 0) == -3
-    assert hip_lib.parrot_e4_bytes(64, 16384, 0) == -3 and "stream engine" in _hip.last_error()
+    assert hip_lib.parrot_e4_bytes(64, 16384, 0) == 8 * (64 + 4) * 1024  # 16 quads in 4 slots
+    assert hip_lib.parrot_e4_bytes(64, 17408, 0) == -3 and "stream engine" in _hip.last_error()
+    assert hip_lib.parrot_e16_bytes(4096, 4096, 0) == 512 * 4 * 16384 == 4096 * 4096 * 2  # bf16: no metadata, no padding here
+    assert hip_lib.parrot_e16_bytes(16, 384, 0) == 2 * 16384  # K is padded to whole 1024-column units
+    # the launch's LDS: 7 ring slots up to K = 11264, 6 beyond (StableLM's 16384-wide MLP input)
+    assert hip_lib.parrot_eng_lds_total(11008, 0, 88 * 272, 32 * 272) == 7 * 17 * 1024 + 120 * 272 + 3552 + 16 * 11 * 32
+    assert hip_lib.parrot_eng_lds_total(16384, 1, 128 * 272, 32 * 272) == 6 * 17 * 1024 + 160 * 272 + 3552 + 16 * 16 * 32
+    assert hip_lib.parrot_eng_lds_total(16384, 1, 128 * 272, 64 * 272) == -3
     assert hip_lib.parrot_eng_lds_bytes(4096, 0, 0, 0) == 32 * 272
     assert hip_lib.parrot_eng_lds_bytes(11008, 128, 1, 8) == 88 * 272
     assert hip_lib.parrot_eng_step(None, None) == -1

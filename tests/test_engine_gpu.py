@@ -8,7 +8,7 @@ pytestmark = pytest.mark.gpu
 import lit_parrot_amd as L  # noqa: E402
 from lit_parrot_amd import _hip  # noqa: E402
 from lit_parrot_amd.config import Config  # noqa: E402
-from lit_parrot_amd.engine import StreamEngine, e4_image  # noqa: E402
+from lit_parrot_amd.engine import StreamEngine, e4_image, e16_image  # noqa: E402
 from lit_parrot_amd.generate import base as gb  # noqa: E402
 from lit_parrot_amd.quantize.gptq import ColBlockQuantizedLinear, pack_nibbles  # noqa: E402
 from lit_parrot_amd.synth import is_linear_key, synthetic_prompt, synthetic_state_dict  # noqa: E402
@@ -102,7 +102,50 @@ def test_e4_repack_is_the_layout_the_header_defines(N, K):
     assert got.shape == want.shape and np.array_equal(got, want)
 
 
+def e16_expected(w: np.ndarray, w2=None) -> np.ndarray:
+    """The E16 image element by element, from the layout include/parrot_hip.h defines: per 8 rows (4 + 4 of a SwiGLU pair)
+    and 1024 columns 16 pieces; in piece i lane l holds columns 1024 Q + 64 i + 8 (l / 8) .. + 7 of row l % 8."""
+    N, K = w.shape
+    dual = w2 is not None
+    nblocks, nq = (N // 4 if dual else N // 8), (K + 1023) // 1024
+    out = np.zeros((nblocks, nq, 16, 64, 8), dtype=np.uint16)
+    for B in range(nblocks):
+        for ln in range(64):
+            r, p = ln & 7, ln >> 3
+            src = w2 if dual and r >= 4 else w
+            row = B * 4 + (r & 3) if dual else B * 8 + r
+            for Q in range(nq):
+                for i in range(16):
+                    k0 = 1024 * Q + 64 * i + 8 * p
+                    if k0 < K:
+                        out[B, Q, i, ln] = src[row, k0:k0 + 8]
+    return out.reshape(-1).view(np.uint8)
+
+
+@pytest.mark.parametrize("N,K,dual", [(16, 128, False), (24, 384, False), (8, 2048, False), (16, 1056, False), (8, 1024, True), (12, 288, True)])
+def test_e16_repack_is_the_layout_the_header_defines(N, K, dual):
+    g = torch.Generator().manual_seed(N * 7 + K)
+    lin = torch.nn.Linear(K, N, bias=False).to(BF)
+    lin.weight.data = torch.randn((N, K), generator=g).to(BF)
+    lin2 = None
+    if dual:
+        lin2 = torch.nn.Linear(K, N, bias=False).to(BF)
+        lin2.weight.data = torch.randn((N, K), generator=g).to(BF)
+    want = e16_expected(lin.weight.data.view(torch.int16).numpy().view(np.uint16),
+                        lin2.weight.data.view(torch.int16).numpy().view(np.uint16) if dual else None)
+    got = e16_image(lin.to(DEV), lin2.to(DEV) if dual else None).cpu().numpy()
+    assert got.shape == want.shape and np.array_equal(got, want)
+
+
 # ------------------------------------------------------------------------------------------------ the step
+def bf16_model(name, **overrides):
+    cfg = Config.from_name(name, **overrides)
+    sd = {k: v.to(BF) for k, v in synthetic_state_dict(cfg, 4321, perturb=True).items()}
+    model = L.GPT(cfg)
+    model.load_state_dict(sd, strict=True)
+    return cfg, sd, model.to(BF).to(DEV).eval()
+
+
 def int4_model(name, tile_cols=128, mode="gptq.int4-g128", **overrides):
     cfg = Config.from_name(name, **overrides)
     sd = {k: v.to(BF) for k, v in synthetic_state_dict(cfg, 4321, perturb=True).items()}
@@ -176,6 +219,34 @@ def test_engine_step_equals_the_multi_launch_step(name):
             assert float(d.max()) <= 1.5e-2 * max(1.0, float(ref.abs().max())) and float(d.mean()) <= 3e-3
 
 
+@pytest.mark.parametrize("name", ["tiny-neox-hs64", "tiny-neox-hs128", "tiny-llama", "tiny-llama-gqa"])
+def test_engine_step_on_bf16_weights_equals_the_multi_launch_step(name):
+    """bf16 Linears (E16 layout) - with LayerNorm + bias, GELU, biases on every Linear, a partial rotary width and the
+    parallel residual of the NeoX family (model.py:166-171), or with the Llama block - against the multi-launch step on the
+    same forced tokens, run to run, and against the oracle."""
+    cfg, sd, model = bf16_model(name)
+    assert StreamEngine.supported(model) is None
+    prompt = synthetic_prompt(cfg, 9, 3)
+    tok_a, log_a = run_session(model, prompt, 24, engine=False)
+    tok_b, log_b = run_session(model, prompt, 24, engine=True, follow=tok_a.to(DEV))
+    assert_same_step(log_a, log_b, tok_a, tok_b, 9)
+    tok_c, log_c = run_session(model, prompt, 24, engine=True)
+    tok_d, log_d = run_session(model, prompt, 24, engine=True, use_graph=False)
+    assert torch.equal(tok_c, tok_d) and torch.equal(log_c, log_d)
+    # a ring window smaller than the sequence
+    tok_e, log_e = run_session(model, prompt, 24, engine=False, S=16)
+    tok_f, log_f = run_session(model, prompt, 24, engine=True, S=16, follow=tok_e.to(DEV))
+    assert_same_step(log_e, log_f, tok_e, tok_f, 9)
+    oracle = om.OracleGPT(cfg, sd, "dense")
+    with torch.no_grad():
+        oracle(tok_c[:9].view(1, -1), 40, torch.arange(9))
+        for i in range(9, 14):
+            ref = oracle(tok_c[i].view(1, 1), 40, torch.tensor([i]))[0, -1].float()
+            d = (log_c[i - 9] - ref).abs()
+            scale = max(1.0, float(ref.abs().max()))
+            assert float(d.max()) <= 2 ** -5 * scale and float(d.mean()) <= 2e-3 * scale, (i, float(d.max()), float(d.mean()))
+
+
 def test_engine_ring_window_and_generate(monkeypatch):
     """generate() end to end on the engine, with a window smaller than the sequence (ring slots) and sampling."""
     cfg, qsd, model = int4_model("tiny-llama")
@@ -233,6 +304,34 @@ def test_engine_at_llama2_7b_width_and_a_long_window():
         tok_c, log_c = run_session(model, prompt, n, engine=True, S=S)
         tok_d, log_d = run_session(model, prompt, n, engine=True, S=S, use_graph=False)
         assert torch.equal(tok_c, tok_d) and torch.equal(log_c, log_d)
+    del model
+    torch.cuda.empty_cache()
+
+
+@torch.no_grad()
+def test_engine_at_stablelm_3b_width():
+    """The bf16 build with the 6-slot ring on StableLM-3B's launch shapes (4096 / 12288 / 16384 / 50688 rows and columns:
+    the MLP's down-projection has 16 units per block, lm_head 24-25 blocks per CU), two layers deep, against the
+    multi-launch step on the same forced tokens, behind a short and a 700-token prompt; run to run identical."""
+    from lit_parrot_amd.config import name_to_config
+    from lit_parrot_amd.synth import build_synthetic_model
+
+    cfg = Config(**{**name_to_config["stablelm-base-alpha-3b"], "n_layer": 2})
+    model = build_synthetic_model(cfg, None, seed=1234, device=DEV)
+    assert StreamEngine.supported(model) is None
+    for T, S, n in ((40, 96, 16), (700, 800, 12)):
+        prompt = synthetic_prompt(cfg, T, 7)
+        tok_a, log_a = run_session(model, prompt, n, engine=False, S=S)
+        tok_b, log_b = run_session(model, prompt, n, engine=True, S=S, follow=tok_a.to(DEV))
+        d = (log_a - log_b).abs()
+        scale = max(1.0, float(log_a.abs().max()))
+        assert float(d.max()) <= 2 ** -5 * scale and float(d.mean()) <= 2e-3 * scale, (T, float(d.max()), float(d.mean()))
+        tok_c, log_c = run_session(model, prompt, n, engine=True, S=S)
+        tok_d, log_d = run_session(model, prompt, n, engine=True, S=S, use_graph=False)
+        assert torch.equal(tok_c, tok_d) and torch.equal(log_c, log_d)
+    a = run_session(model, synthetic_prompt(cfg, 20, 9), 200, engine=True, S=128)
+    b = run_session(model, synthetic_prompt(cfg, 20, 9), 200, engine=True, S=128)
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
     del model
     torch.cuda.empty_cache()
 

@@ -34,8 +34,8 @@ with torch.no_grad():
     for _ in range(steps):
         sess.step()
         torch.cuda.synchronize()
-        d = dbg.cpu().view(-1, 8).double()
-        raw = dbg.cpu().view(-1, 8)
+        d = dbg.cpu().view(-1, 16).double()
+        raw = dbg.cpu().view(-1, 16)
         acc = d if acc is None else acc + d
     sess.eng.check_error()
     allc = sess.eng.dbg_all.cpu().view(-1, 256, 2).double() / 100.0  # last step: [op][cu][ready, done] in us
@@ -43,7 +43,7 @@ d = acc / steps
 t0 = d[0, 0]
 names = []
 for i in range(cfg.n_layer):
-    names += ["qkv", "attn", "proj", "fc", "down"]
+    names += ["qkv", "fc", "attn", "proj", "down"] if cfg.parallel_residual else ["qkv", "attn", "proj", "fc", "down"]
 names.append("lm_head")
 agg = {}
 for k, n in enumerate(names):
@@ -63,6 +63,11 @@ for k, n in enumerate(names):
         extra = ""
         if n != "attn" and k > 0:
             extra = f" | gate +{(d[k, 6] - d[k, 0]) / 100.0:.2f} sweep +{(d[k, 7] - d[k, 6]) / 100.0:.2f} norm+bars +{(d[k, 1] - d[k, 7]) / 100.0:.2f} gate polls {gate_spins}"
+            if d[k, 8] > 0:
+                t9 = d[k, 9] if d[k, 9] > 0 else d[k, 8]
+                extra += f" [stat1 +{(d[k, 8] - d[k, 7]) / 100.0:.2f} stat2 +{(t9 - d[k, 8]) / 100.0:.2f} norm slot +{(d[k, 10] - t9) / 100.0:.2f} apply +{(d[k, 11] - d[k, 10]) / 100.0:.2f} bar +{(d[k, 1] - d[k, 11]) / 100.0:.2f}]"
+            else:
+                extra += f" [apply +{(d[k, 11] - d[k, 7]) / 100.0:.2f} bar +{(d[k, 1] - d[k, 11]) / 100.0:.2f}]"
         if n == "attn":
             extra = f" | units +{(d[k, 6] - d[k, 1]) / 100.0:.2f} merge+bar +{(d[k, 7] - d[k, 6]) / 100.0:.2f} tail +{(d[k, 2] - d[k, 7]) / 100.0:.2f}"
         print(f"op {k:3d} {n:8s} enter {enter:9.2f} us  input ready +{ready - enter:6.2f}  units done +{done - ready:6.2f} (waiting for slots {d[k, 3] / 100.0:5.2f})"
