@@ -248,12 +248,14 @@ int parrot_argmax_advance(const void* logits, int V, int64_t* tokens, int32_t* p
 
 typedef struct parrot_eng_op {
     int32_t type;          /* PARROT_ENG_* */
-    int32_t epilogue;      /* PARROT_EPI_NONE / RESIDUAL / GELU / SWIGLU or PARROT_ENG_EPI_LOGITS */
+    int32_t epilogue;      /* GEMV: PARROT_EPI_NONE / RESIDUAL / GELU / SWIGLU or PARROT_ENG_EPI_LOGITS;
+                              ATTN: 0 the whole op, 1 / 2 its halves as two ops (1: the CU's keys -> partial state; 2: the
+                              group's leader merges the partial states into the heads) with other ops between them */
     int32_t K;             /* input elements (GEMV) */
     int32_t nblocks;       /* 8-row blocks of the matrix: N / 8, or N / 4 for the SwiGLU pair */
     int32_t nq;            /* units per block = ceil(K / 1024) */
     int32_t buf;           /* GEMV: which of the two LDS activation buffers this op's input uses (consecutive GEMVs
-                              alternate); ATTN: 1 = the previous op read buffer 0 (the attention scratch): barrier first */
+                              alternate); ATTN: which one holds the scratch (= the state's attn_buf) */
     int32_t norm_kind;     /* norm fused in front: 0 none, 1 RMSNorm, 2 LayerNorm */
     float norm_eps;
     int32_t in_embedding;  /* the input vector is wte[tokens[pos]] (first block) */
@@ -262,7 +264,10 @@ typedef struct parrot_eng_op {
     int32_t res_in;        /* RESIDUAL: the residual is the CU's rows of 0: x (the block's input), 1: x + attention branch */
     int32_t res_out;       /* RESIDUAL: ... and the sum becomes the CU's rows of 0 / 1 */
     int32_t publish;       /* 1: the outputs go out as granules (`out`); 0: they stay in the CU (parallel residual: x + attn) */
-    int32_t no_gather;     /* 1: the input is already in LDS buffer `buf`: the previous Linear normalised it there (norm2_w) */
+    int32_t no_gather;     /* GEMV 1: the input is already in LDS buffer `buf`: an earlier Linear normalised it there
+                              (norm2_w); ATTN 1: barrier first (the scratch buffer's last readers may still be at work) */
+    int32_t blk_part;      /* GEMV: this op covers part blk_part of blk_parts of every CU's blocks of the Linear */
+    int32_t blk_parts;     /*       (0 or 1: all of them); not with PARROT_EPI_RESIDUAL */
     int32_t reserved;
     const void* W;         /* E4 / E16 weights */
     const void* norm_w;    /* K bf16 */
@@ -295,6 +300,8 @@ typedef struct parrot_eng_state {
     int32_t lds_buf0_bytes, lds_buf1_bytes; /* from parrot_eng_lds_bytes */
     int32_t kmax;               /* the largest K of any op: above 11264 the build with a 6-slot ring runs */
     int32_t wfmt;               /* PARROT_ENG_W_*: the one weight format of every Linear of the launch */
+    int32_t attn_buf;           /* which LDS buffer the attention ops use as scratch (must hold it) */
+    int32_t reserved;
     uint64_t* arg;              /* 2 * 256 granules: every CU's arg-max candidate {value, index} */
     uint64_t* dbg;              /* NULL, or nops * 16 words: 100 MHz stamps of workgroup 0 (diagnostic runs only) */
     uint64_t* dbg_all;          /* NULL, or nops * 256 * 2 words: {input ready, units done} stamps of every workgroup */

@@ -41,7 +41,7 @@ class EngOp(C.Structure):  # parrot_eng_op_t
     _fields_ = (
         [(n, C.c_int32) for n in ("type", "epilogue", "K", "nblocks", "nq", "buf", "norm_kind")]
         + [("norm_eps", C.c_float)]
-        + [(n, C.c_int32) for n in ("in_embedding", "res_embedding", "wfmt", "res_in", "res_out", "publish", "no_gather", "reserved")]
+        + [(n, C.c_int32) for n in ("in_embedding", "res_embedding", "wfmt", "res_in", "res_out", "publish", "no_gather", "blk_part", "blk_parts", "reserved")]
         + [(n, C.c_void_p) for n in ("W", "norm_w", "norm_b", "bias", "norm2_w", "norm2_b", "inp", "out", "part", "k_cache", "v_cache")]
     )
 
@@ -51,7 +51,7 @@ class EngState(C.Structure):  # parrot_eng_state_t
         [("ops", C.c_void_p), ("nops", C.c_int32), ("d", C.c_int32)]
         + [(n, C.c_void_p) for n in ("tokens", "pos", "epoch", "err", "wte", "rope_cos", "rope_sin")]
         + [(n, C.c_int32) for n in ("n_elem", "n_groups", "q_per_kv", "hs", "S", "V", "rsqrt_mode", "nsplit", "greedy",
-                                    "lds_buf0_bytes", "lds_buf1_bytes", "kmax", "wfmt")]
+                                    "lds_buf0_bytes", "lds_buf1_bytes", "kmax", "wfmt", "attn_buf", "reserved")]
         + [(n, C.c_void_p) for n in ("arg", "dbg", "dbg_all")]
     )
 

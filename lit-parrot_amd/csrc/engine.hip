@@ -289,7 +289,8 @@ __device__ __forceinline__ void eng_wait_lds_ge_tight(const EngState& st, const 
 #ifndef ENG_CYCLIC
 #define ENG_CYCLIC 0
 #endif
-__device__ __forceinline__ void eng_block_range(int nblocks, int cu, int& bs, int& nb, int& bstep) {
+__device__ __forceinline__ void eng_block_range(const EngOp* op, int cu, int& bs, int& nb, int& bstep) {
+    const int nblocks = op->nblocks;
     if (ENG_CYCLIC) {
         bs = cu;
         nb = (nblocks - cu + ENG_WGS - 1) / ENG_WGS;
@@ -299,6 +300,11 @@ __device__ __forceinline__ void eng_block_range(int nblocks, int cu, int& bs, in
         bs = (int)(((int64_t)cu * nblocks) / ENG_WGS);
         nb = (int)(((int64_t)(cu + 1) * nblocks) / ENG_WGS) - bs;
         bstep = 1;
+    }
+    if (op->blk_parts > 1) {  // this op is part blk_part of blk_parts of the Linear: that share of the CU's blocks
+        const int l0 = nb * op->blk_part / op->blk_parts, l1 = nb * (op->blk_part + 1) / op->blk_parts;
+        bs += l0 * bstep;
+        nb = l1 - l0;
     }
 }
 // key range of CU c in an attention op: group g, split s; keys [kb, ke) of the n_valid admitted slots
@@ -339,6 +345,7 @@ __device__ __forceinline__ void eng_loader(const EngState& st, const EngCtx& c, 
     int seq = 0;                  // sequence number of the next slot of the stream (all loaders count alike)
     int mine = 0, pub = 0;        // own slots issued / announced
     int inflight = 0;             // own pieces in flight
+    uint64_t stalled = 0;         // diagnostic: 100 MHz ticks spent waiting for a free ring slot while issuing the current op
     __builtin_amdgcn_s_setprio(3);  // a handful of instructions per slot: never behind the consumers' arithmetic
 
     // the loader's own bookkeeping lives in two registers, one lane per entry (an LDS round trip per look-up was a fifth
@@ -363,7 +370,9 @@ __device__ __forceinline__ void eng_loader(const EngState& st, const EngCtx& c, 
         const uint32_t target = (uint32_t)__builtin_amdgcn_readlane(exp_v, r);
         if (lds_ld(c.fx + EF_CONS + r * 4) != target) {
             while (pub < mine) publish_oldest();  // never sleep on a free slot with landed data unannounced
+            const uint64_t t0 = (ENG_STAMPS && st.dbg != nullptr) ? __builtin_amdgcn_s_memrealtime() : 0;
             eng_wait_lds_ge(st, c, EF_CONS + r * 4, target, 0x10000000u | (uint32_t)seq);
+            if (ENG_STAMPS && st.dbg != nullptr) stalled += __builtin_amdgcn_s_memrealtime() - t0;  // diagnostic: ring full
         }
         while (mine - pub >= ENG_MAXFLY || inflight + np > 60) publish_oldest();
         if (k > (int)lds_ld(c.fx + EF_CUR))
@@ -385,6 +394,8 @@ __device__ __forceinline__ void eng_loader(const EngState& st, const EngCtx& c, 
         if ((ENG_STAMPS && st.dbg != nullptr) && c.cu == 0 && c.lane == 0 && li == 0) {  // diagnostic: when the loader reaches the op, and what it has announced by then
             st.dbg[k * 16 + 4] = __builtin_amdgcn_s_memrealtime();
             st.dbg[k * 16 + 5] = (uint64_t)seq | ((uint64_t)(li + pub * NLOAD) << 32);
+            if (k > 0) st.dbg[(k - 1) * 16 + 12] = stalled;  // ring-full time while issuing the previous op's slots
+            stalled = 0;
         }
         if (op->type == PARROT_ENG_GEMV) {
             if (op->norm_kind != 0) {
@@ -412,7 +423,7 @@ __device__ __forceinline__ void eng_loader(const EngState& st, const EngCtx& c, 
                 }
             }
             int bs, nb, bstep;
-            eng_block_range(op->nblocks, c.cu, bs, nb, bstep);
+            eng_block_range(op, c.cu, bs, nb, bstep);
             const int nq = op->nq;
             if (CF::WF == PARROT_ENG_W_E16) {
                 // bf16: a slot is one unit = 16 pieces (8 rows x 1024 columns); the first slot of a block carries the block's
@@ -456,7 +467,7 @@ __device__ __forceinline__ void eng_loader(const EngState& st, const EngCtx& c, 
                     }
                 }
             }
-        } else {
+        } else if (op->epilogue != 2) {  // (the second half of a split attention op streams nothing)
             const EngKeys ky = eng_keys<HS>(st, c.cu, c.pos);
             const int64_t grp_bytes = (int64_t)st.S * HS * 2;
             const unsigned char* kg = reinterpret_cast<const unsigned char*>(op->k_cache) + (int64_t)ky.g * grp_bytes;
@@ -719,7 +730,7 @@ __device__ __forceinline__ void eng_gemv(const EngState& st, const EngCtx& c0, E
     if (w.cw == 0 && c.lane == 0) lds_st(c.fx + EF_CUR, (uint32_t)k);
     eng_stamp(st, c, w, k, 1);
     int bs, nb, bstep;
-    eng_block_range(op->nblocks, c.cu, bs, nb, bstep);
+    eng_block_range(op, c.cu, bs, nb, bstep);
     constexpr bool e16 = CF::WF == PARROT_ENG_W_E16;
     const int nq = op->nq, spb = e16 ? nq : (nq + 3) >> 2;
     const unsigned char* buf = op->buf ? c.buf1 : c.buf0;
@@ -852,22 +863,22 @@ __device__ __forceinline__ void eng_gemv(const EngState& st, const EngCtx& c0, E
 
 // ---- attention op: split + RoPE + KV append + softmax(q k^T / sqrt(hs)) v over the CU's key range, partial states to the
 // group's leader CU, which merges them into the heads
+// Two halves, run back to back for the sequential-residual block (phase 0) or as two ops with a part of the MLP's
+// up-projection between them (parallel residual: phases 1 and 2 - the partial states travel while weights stream):
+//   local:   the CU's key range -> its partial state, to the group's leader (or kept in LDS when the CU is the only split)
+//   combine: the leader merges the splits into the heads and hands them over
+// The scratch lives in LDS activation buffer op->buf; op->no_gather = 1 asks for a barrier first (the buffer's last readers
+// may still be at work: the waves come here straight from another Linear's units).
 template <class CF, int HS, int HQ>
-__device__ __forceinline__ void eng_attn(const EngState& st, const EngCtx& c0, EngCons& w, const EngOp* op, int k) {
+__device__ __forceinline__ bool eng_attn_local(const EngState& st, const EngCtx& c0, EngCons& w, const EngOp* op, int k) {
     constexpr int LPR = HS / 8, KPP = 64 / LPR, PW = HS + 2;
     EngCtx c = c0;
     asm volatile("" : "+v"(c.lane));
     eng_stamp(st, c, w, k, 0);
     const EngKeys ky = eng_keys<HS>(st, c.cu, c.pos);
-    // scratch in activation buffer 0.  Behind the QKV Linear its last readers passed the barriers of that op's gather; behind
-    // a Linear that read buffer 0 itself (parallel residual: the MLP's up-projection runs between QKV and attention) the
-    // waves meet first
-    if (op->buf) eng_cbar<CF>(st, c, w);
-    if (!ky.part) {
-        eng_cbar<CF>(st, c, w);
-        return;
-    }
-    unsigned char* sc = c.buf0;
+    if (op->no_gather) eng_cbar<CF>(st, c, w);
+    if (!ky.part) return false;
+    unsigned char* sc = op->buf ? c.buf1 : c.buf0;
     uint32_t* raw = reinterpret_cast<uint32_t*>(sc);                                      // [(HQ + 2) * HS / 2] bf16 pairs
     float* wpart = reinterpret_cast<float*>(sc + (HQ + 2) * HS * 2);                      // [NC][HQ][PW]
     float* stage = wpart + CF::NC * HQ * PW;                                              // [HQ][nsplit][PW]
@@ -1047,6 +1058,17 @@ __device__ __forceinline__ void eng_attn(const EngState& st, const EngCtx& c0, E
             if (c.lane == 1) st_gran(pg + HS + 1, __float_as_uint(L), c.epoch);
         }
     }
+    return true;
+}
+
+template <class CF, int HS, int HQ>
+__device__ __forceinline__ void eng_attn_combine(const EngState& st, const EngCtx& c0, EngCons& w, const EngOp* op, int k) {
+    constexpr int PW = HS + 2;
+    EngCtx c = c0;
+    asm volatile("" : "+v"(c.lane));
+    const EngKeys ky = eng_keys<HS>(st, c.cu, c.pos);
+    unsigned char* sc = op->buf ? c.buf1 : c.buf0;
+    float* stage = reinterpret_cast<float*>(sc + (HQ + 2) * HS * 2) + CF::NC * HQ * PW;
     if (ky.s == 0) {  // the group's leader CU merges the splits into the heads: every wave fetches a share of the partial states
         const int cnt = HQ * ky.ns * PW;  // the group's heads lie back to back
         const uint64_t* pg = op->part + (int64_t)ky.g * HQ * ky.ns * PW;
@@ -1101,6 +1123,23 @@ __device__ __forceinline__ void eng_attn(const EngState& st, const EngCtx& c0, E
         }
     }
     eng_cbar<CF>(st, c, w);  // the scratch is free again (the next op's input goes into this buffer)
+}
+
+template <class CF, int HS, int HQ>
+__device__ __forceinline__ void eng_attn(const EngState& st, const EngCtx& c, EngCons& w, const EngOp* op, int k) {
+    const int phase = op->epilogue;  // 0: the whole op; 1 / 2: its halves
+    if (phase != 2) {
+        const bool part = eng_attn_local<CF, HS, HQ>(st, c, w, op, k);
+        if (phase == 0) {
+            if (part)
+                eng_attn_combine<CF, HS, HQ>(st, c, w, op, k);
+            else
+                eng_cbar<CF>(st, c, w);
+        }
+    } else {
+        eng_stamp(st, c, w, k, 0);
+        if (eng_keys<HS>(st, c.cu, c.pos).part) eng_attn_combine<CF, HS, HQ>(st, c, w, op, k);
+    }
     eng_stamp(st, c, w, k, 2);
     if ((ENG_STAMPS && st.dbg != nullptr) && c.cu == 0 && w.cw == 0 && c.lane == 0) st.dbg[k * 16 + 3] = w.waited;
     w.waited = 0;
@@ -1397,7 +1436,9 @@ int parrot_eng_step(const parrot_eng_state_t* state_host, void* stream) {
     PARROT_REQUIRE(st.S >= 1 && st.V >= 1 && st.d >= 1, "eng_step: bad S / V / d");
     PARROT_REQUIRE(st.lds_buf0_bytes > 0 && st.lds_buf0_bytes % 16 == 0 && st.lds_buf1_bytes > 0 && st.lds_buf1_bytes % 16 == 0,
                    "eng_step: LDS buffer sizes must be positive multiples of 16");
-    PARROT_REQUIRE(st.lds_buf0_bytes >= eng_attn_scratch_bytes(st.hs, st.q_per_kv, st.nsplit), "eng_step: LDS buffer 0 smaller than the attention scratch");
+    PARROT_REQUIRE(st.attn_buf == 0 || st.attn_buf == 1, "eng_step: attn_buf must be 0 or 1");
+    PARROT_REQUIRE((st.attn_buf ? st.lds_buf1_bytes : st.lds_buf0_bytes) >= eng_attn_scratch_bytes(st.hs, st.q_per_kv, st.nsplit),
+                   "eng_step: LDS buffer %d smaller than the attention scratch", st.attn_buf);
     PARROT_REQUIRE(st.kmax >= 1, "eng_step: kmax (the largest input of any op) must be set");
     {
         const int nqm = (st.kmax + 1023) / 1024;

@@ -100,15 +100,24 @@ class StreamEngine:
         dev = next(model.parameters()).device
         if dev.type != "cuda" or torch.cuda.get_device_properties(dev).multi_processor_count < ENG_WGS:
             return f"the engine keeps {ENG_WGS} workgroups resident, one per CU: the device has fewer CUs"
+        wfmt = ENG_W_E4 if isinstance(linears[0], ColBlockQuantizedLinear) else ENG_W_E16
+        b0, b1, _ = StreamEngine._lds_buffers(c)
+        if b0 < 0 or b1 < 0 or _hip.load().parrot_eng_lds_total(max(c.intermediate_size, c.n_embd), wfmt, b0, b1) < 0:
+            return _hip.last_error()
+        return None
+
+    @staticmethod
+    def _lds_buffers(c):
+        """Bytes of the two LDS activation buffers and which one the attention ops use as scratch.  Buffer 0 holds the widest
+        input (the MLP's hidden vector); sequential residual: the attention scratch too (the buffer is idle between the QKV
+        Linear and the out-projection).  Parallel residual: the MLP's up-projection, whose input sits in buffer 0, runs
+        around the attention ops, so their scratch goes to buffer 1."""
         lib = _hip.load()
         nsplit = min(8, ENG_WGS // c.n_query_groups)
         kmax = max(c.intermediate_size, c.n_embd)
-        b0 = lib.parrot_eng_lds_bytes(kmax, c.head_size, c.q_per_kv, nsplit)
-        b1 = lib.parrot_eng_lds_bytes(c.n_embd, 0, 0, 0)
-        wfmt = ENG_W_E4 if isinstance(linears[0], ColBlockQuantizedLinear) else ENG_W_E16
-        if b0 < 0 or b1 < 0 or lib.parrot_eng_lds_total(kmax, wfmt, b0, b1) < 0:
-            return _hip.last_error()
-        return None
+        if c.parallel_residual:
+            return lib.parrot_eng_lds_bytes(kmax, 0, 0, 0), lib.parrot_eng_lds_bytes(c.n_embd, c.head_size, c.q_per_kv, nsplit), 1
+        return lib.parrot_eng_lds_bytes(kmax, c.head_size, c.q_per_kv, nsplit), lib.parrot_eng_lds_bytes(c.n_embd, 0, 0, 0), 0
 
     @staticmethod
     def faster_than_multi_launch(model, window: int, int4_min_window: int) -> bool:
@@ -128,6 +137,7 @@ class StreamEngine:
         L, d, hs, inter, V = c.n_layer, c.n_embd, c.head_size, c.intermediate_size, c.padded_vocab_size
         nsplit = min(8, ENG_WGS // c.n_query_groups)
         swiglu = c._mlp_class == "LLaMAMLP"
+        attn_buf = self._lds_buffers(c)[2]
         self.logits = torch.zeros((1, V), dtype=torch.bfloat16, device=dev)
         # granule buffers, per layer (written once per launch each): qkv, attention partials, heads, x after the
         # attention branch (sequential residual only), MLP hidden, x after the block; zero = "never written" (the epoch
@@ -147,20 +157,26 @@ class StreamEngine:
         self.images = []  # keeps the E4 / E16 images alive
         ops_list: List[EngOp] = []
 
+        images = {}
+
         def gemv(lin, nblocks: int, epilogue: int, buf: int, inp: Optional[int], out: Optional[int], *, partner=None, norm=None,
-                 norm2=None, no_gather=False, in_emb=False, res_emb=False, res_in=0, res_out=0, publish=True) -> None:
+                 norm2=None, no_gather=False, in_emb=False, res_emb=False, res_in=0, res_out=0, publish=True, part=(0, 1)) -> None:
             op = EngOp()
             K = lin.in_features
             op.type, op.epilogue, op.K, op.nblocks, op.nq, op.buf = ENG_GEMV, epilogue, K, nblocks, (K + 1023) // 1024, buf
-            if isinstance(lin, ColBlockQuantizedLinear):
-                img, op.wfmt = e4_image(lin, partner), ENG_W_E4
-            else:
-                img, op.wfmt = e16_image(lin, partner), ENG_W_E16
-                if lin.bias is not None:
-                    if partner is not None:
-                        raise ParrotHipError("stream engine: a SwiGLU pair with biases is not built")
-                    op.bias = ptr(lin.bias.data)
-            self.images.append(img)
+            op.blk_part, op.blk_parts = part
+            if part[1] > 1 and epilogue == EPI_RESIDUAL:
+                raise ParrotHipError("stream engine: a Linear with a residual epilogue is not split into parts")
+            e4 = isinstance(lin, ColBlockQuantizedLinear)
+            op.wfmt = ENG_W_E4 if e4 else ENG_W_E16
+            if not e4 and lin.bias is not None:
+                if partner is not None:
+                    raise ParrotHipError("stream engine: a SwiGLU pair with biases is not built")
+                op.bias = ptr(lin.bias.data)
+            img = images.get(id(lin))
+            if img is None:
+                img = images[id(lin)] = e4_image(lin, partner) if e4 else e16_image(lin, partner)
+                self.images.append(img)
             op.W, op.inp, op.out = img.data_ptr(), inp, out
             if norm is not None:
                 op.norm_w, op.norm_eps = ptr(norm.weight.data), float(norm.eps)
@@ -197,12 +213,21 @@ class StreamEngine:
                 # up-projection starts without a gather and runs between QKV and attention - by the time its weights
                 # have streamed the QKV vector has long arrived everywhere.  The out-projection keeps x + attn in the CU
                 # that owns the rows, the down-projection adds its rows and hands the block's output over.
-                gemv(up, up_blocks, up_epi, 0, None, gran(i, "h"), partner=partner, no_gather=True)
-                at.buf = 1  # the up-projection's input sits in buffer 0, the attention scratch
+                # The attention op runs as two ops with thirds of the up-projection around them: while the partial states
+                # of a head travel to its leader CU, and the heads to everybody, weights keep streaming.
+                gemv(up, up_blocks, up_epi, 0, None, gran(i, "h"), partner=partner, no_gather=True, part=(0, 3))
+                at.epilogue, at.buf, at.no_gather = 1, attn_buf, 1
                 ops_list.append(at)
+                gemv(up, up_blocks, up_epi, 0, None, gran(i, "h"), partner=partner, no_gather=True, part=(1, 3))
+                at2 = EngOp()
+                at2.type, at2.epilogue, at2.buf = ENG_ATTN, 2, attn_buf
+                at2.inp, at2.out, at2.part, at2.k_cache, at2.v_cache = at.inp, at.out, at.part, at.k_cache, at.v_cache
+                ops_list.append(at2)
+                gemv(up, up_blocks, up_epi, 0, None, gran(i, "h"), partner=partner, no_gather=True, part=(2, 3))
                 gemv(block.attn.proj, d // 8, EPI_RESIDUAL, 1, gran(i, "y"), None, res_emb=first, res_in=0, res_out=1, publish=False)
                 gemv(mlp.proj, d // 8, EPI_RESIDUAL, 0, gran(i, "h"), gran(i, "xb"), res_in=1, res_out=0)
             else:
+                at.buf = attn_buf
                 ops_list.append(at)
                 gemv(block.attn.proj, d // 8, EPI_RESIDUAL, 0, gran(i, "y"), gran(i, "xa"), res_emb=first)
                 gemv(up, up_blocks, up_epi, 1, gran(i, "xa"), gran(i, "h"), partner=partner, norm=block.norm_2)
@@ -224,8 +249,7 @@ class StreamEngine:
         st.V, st.rsqrt_mode, st.nsplit, st.greedy = V, ops.RMSNORM_RSQRT_MODE, nsplit, int(greedy)
         st.kmax = max(inter, d)
         st.wfmt = ops_list[0].wfmt
-        st.lds_buf0_bytes = self.lib.parrot_eng_lds_bytes(st.kmax, hs, c.q_per_kv, nsplit)
-        st.lds_buf1_bytes = self.lib.parrot_eng_lds_bytes(d, 0, 0, 0)
+        st.lds_buf0_bytes, st.lds_buf1_bytes, st.attn_buf = self._lds_buffers(c)
         st.arg = self.granules.data_ptr() + 8 * L * per_layer
         self.state = st
         self.n_ops = len(ops_list)

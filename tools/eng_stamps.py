@@ -43,13 +43,14 @@ d = acc / steps
 t0 = d[0, 0]
 names = []
 for i in range(cfg.n_layer):
-    names += ["qkv", "fc", "attn", "proj", "down"] if cfg.parallel_residual else ["qkv", "attn", "proj", "fc", "down"]
+    names += ["qkv", "fc0", "attn1", "fc1", "attn2", "fc2", "proj", "down"] if cfg.parallel_residual else ["qkv", "attn", "proj", "fc", "down"]
 names.append("lm_head")
 agg = {}
 for k, n in enumerate(names):
     enter, ready, done = (d[k, 0] - t0) / 100.0, (d[k, 1] - t0) / 100.0, (d[k, 2] - t0) / 100.0
     nxt = (d[k + 1, 0] - t0) / 100.0 if k + 1 < len(names) else done
-    a = agg.setdefault(n, [0.0, 0.0, 0.0, 0, 0.0, 0.0])
+    a = agg.setdefault(n, [0.0, 0.0, 0.0, 0, 0.0, 0.0, 0.0])
+    a[6] += d[k, 12] / 100.0
     a[0] += ready - enter
     a[1] += done - ready
     a[2] += nxt - done
@@ -61,20 +62,20 @@ for k, n in enumerate(names):
     a[5] += lead
     if k < 11 or k >= len(names) - 6:
         extra = ""
-        if n != "attn" and k > 0:
+        if not n.startswith("attn") and k > 0:
             extra = f" | gate +{(d[k, 6] - d[k, 0]) / 100.0:.2f} sweep +{(d[k, 7] - d[k, 6]) / 100.0:.2f} norm+bars +{(d[k, 1] - d[k, 7]) / 100.0:.2f} gate polls {gate_spins}"
             if d[k, 8] > 0:
                 t9 = d[k, 9] if d[k, 9] > 0 else d[k, 8]
                 extra += f" [stat1 +{(d[k, 8] - d[k, 7]) / 100.0:.2f} stat2 +{(t9 - d[k, 8]) / 100.0:.2f} norm slot +{(d[k, 10] - t9) / 100.0:.2f} apply +{(d[k, 11] - d[k, 10]) / 100.0:.2f} bar +{(d[k, 1] - d[k, 11]) / 100.0:.2f}]"
             else:
                 extra += f" [apply +{(d[k, 11] - d[k, 7]) / 100.0:.2f} bar +{(d[k, 1] - d[k, 11]) / 100.0:.2f}]"
-        if n == "attn":
+        if n in ("attn", "attn1"):
             extra = f" | units +{(d[k, 6] - d[k, 1]) / 100.0:.2f} merge+bar +{(d[k, 7] - d[k, 6]) / 100.0:.2f} tail +{(d[k, 2] - d[k, 7]) / 100.0:.2f}"
         print(f"op {k:3d} {n:8s} enter {enter:9.2f} us  input ready +{ready - enter:6.2f}  units done +{done - ready:6.2f} (waiting for slots {d[k, 3] / 100.0:5.2f})"
               f"  loader lead {lead:6.2f} us, seq/pub at reach {int(raw[k, 5]) & 0xffffffff}/{int(raw[k, 5]) >> 32}{extra}")
-print("mean per op type (us): wait+gather | own units (of which waiting for slots) | to next op | loader lead")
+print("mean per op type (us): wait+gather | own units (of which waiting for slots) | to next op | loader lead | loader 0 stalled on a full ring while issuing the op")
 for n, a in agg.items():
-    print(f"  {n:8s} {a[0] / a[3]:7.2f} {a[1] / a[3]:7.2f} ({a[4] / a[3]:5.2f}) {a[2] / a[3]:7.2f} {a[5] / a[3]:7.2f}   x{a[3]}")
+    print(f"  {n:8s} {a[0] / a[3]:7.2f} {a[1] / a[3]:7.2f} ({a[4] / a[3]:5.2f}) {a[2] / a[3]:7.2f} {a[5] / a[3]:7.2f} {a[6] / a[3]:7.2f}   x{a[3]}")
 print(f"token (workgroup 0, wave 1): {(d[len(names) - 1, 2] - t0) / 100.0:.1f} us")
 
 # skew across the 256 workgroups (last step): spread of the "units done" and "input ready" times per op type
