@@ -57,6 +57,9 @@ namespace parrot {
 #ifndef ENG_SPIN_MODE
 #define ENG_SPIN_MODE (-1)  // -1: by weight format (bf16: waiting waves drop their priority, +0.8 %; int4: plain spin, +0.7 %)
 #endif
+#ifndef ENG_LEADER_SPREAD
+#define ENG_LEADER_SPREAD 1
+#endif
 #ifndef ENG_AB_NOGSTAMP
 #define ENG_AB_NOGSTAMP 0
 #endif
@@ -1069,7 +1072,10 @@ __device__ __forceinline__ void eng_attn_combine(const EngState& st, const EngCt
     const EngKeys ky = eng_keys<HS>(st, c.cu, c.pos);
     unsigned char* sc = op->buf ? c.buf1 : c.buf0;
     float* stage = reinterpret_cast<float*>(sc + (HQ + 2) * HS * 2) + CF::NC * HQ * PW;
-    if (ky.s == 0) {  // the group's leader CU merges the splits into the heads: every wave fetches a share of the partial states
+    // the group's leader CU merges the splits into the heads: every wave fetches a share of the partial states.  The leader is
+    // split g % ns of group g: with split 0 every leader sat on XCD 0 (workgroup id % 8), whose CUs then ran late into
+    // every later hand-off
+    if (ky.s == (ENG_LEADER_SPREAD ? ky.g % ky.ns : 0)) {
         const int cnt = HQ * ky.ns * PW;  // the group's heads lie back to back
         const uint64_t* pg = op->part + (int64_t)ky.g * HQ * ky.ns * PW;
         constexpr int NLD = (2 * 8 * PW + 63) / 64, NPW = (NLD + CF::NC - 1) / CF::NC;  // HQ <= 2, nsplit <= 8
