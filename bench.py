@@ -102,29 +102,31 @@ PMC_KERNEL_PREFIX = {"w4_gemv": "w4_gemv_kernel<1, false", "w4_gemv_dual": "w4_g
                      "w8_gemv": "w8_gemv_kernel", "attn_fused_decode": "attn_fused_decode_kernel", "eng_token": "eng_token_kernel"}
 
 
-def pmc_traffic(kernel: str):
-    """HBM bytes per launch of ``kernel`` from the newest committed PMC summary (profiles/*_pmc_traffic.json, written by
+def pmc_traffic(kernel: str, run: str = "llama2-7b-int4"):
+    """HBM bytes per launch of ``kernel`` in the run ``run`` (a workload name, "-engine" appended when the headline runs
+    on the stream engine) from the newest committed PMC summary (profiles/<tag>_<run>_pmc_traffic.json, written by
     tools/summarize_profiles.py from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this benchmark).
     Counters cannot be collected inside the timed run; returns (bytes per launch or None, source file, problem or None).
     A summary without a kernel of the expected name is STALE (the kernels changed since it was taken): that is reported as a
-    problem, printed on stderr and asserted by tests/test_bench_host.py - never papered over with an old number."""
+    problem, printed on stderr and asserted by tests/test_replicas_gloo.py - never papered over with an old number."""
     files = sorted((REPO / "profiles").glob("*_pmc_traffic.json"))
     prefix = PMC_KERNEL_PREFIX.get(kernel)
     if not files or prefix is None:
         return None, None, "no PMC summary for this kernel"
     newest = files[-1].name.split("_")[0]  # the round tag: only summaries of the newest measurement pass count
-    files = [f for f in files if f.name.split("_")[0] == newest]
-    for f in reversed(files):
-        entries = json.loads(f.read_text())["kernels"]
-        tot_b = tot_n = 0.0
-        for name, v in entries.items():
-            if name.startswith(prefix) and "hbm_bytes_per_launch_corrected" in v:
-                n = v.get("launches_FETCH_SIZE", 1)
-                tot_b += v["hbm_bytes_per_launch_corrected"] * n
-                tot_n += n
-        if tot_n:
-            return tot_b / tot_n, f.name, None
-    return None, files[-1].name, f"STALE: the {newest} PMC summaries hold no kernel named {prefix}*"
+    f = REPO / "profiles" / f"{newest}_{run}_pmc_traffic.json"
+    if not f.exists():
+        return None, None, f"the {newest} measurement pass holds no PMC summary of {run}"
+    entries = json.loads(f.read_text())["kernels"]
+    tot_b = tot_n = 0.0
+    for name, v in entries.items():
+        if name.startswith(prefix) and "hbm_bytes_per_launch_corrected" in v:
+            n = v.get("launches_FETCH_SIZE", 1)
+            tot_b += v["hbm_bytes_per_launch_corrected"] * n
+            tot_n += n
+    if tot_n:
+        return tot_b / tot_n, f.name, None
+    return None, f.name, f"STALE: {f.name} holds no kernel named {prefix}*"
 
 
 def rank_env():
@@ -377,8 +379,9 @@ def main() -> None:
         bytes_per_launch = kb[dom][0] / kb[dom][1]
         avg_s = stats[dom][0] / stats[dom][1] * 1e-3
         achieved = bytes_per_launch / avg_s / 1e9
-        traffic, traffic_src, traffic_problem = pmc_traffic(dom) if args.workload == "llama2-7b-int4" else (None, None, None)
-        if traffic_problem and args.workload == "llama2-7b-int4":
+        run = args.workload + ("-engine" if args.workload == "llama2-7b-int4" and sess.eng is not None else "")
+        traffic, traffic_src, traffic_problem = pmc_traffic(dom, run)
+        if traffic_problem:
             print(f"bench.py: roofline.traffic unavailable - {traffic_problem}", file=sys.stderr, flush=True)
         roofline = {"kernel": dom, "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_src, "traffic_problem": traffic_problem,

@@ -107,7 +107,9 @@ def test_committed_pmc_summary_names_the_running_kernels():
     sys.path.insert(0, str(REPO))
     import bench
 
-    for kernel in ("w4_gemv", "w4_gemv_dual"):
-        traffic, src, problem = bench.pmc_traffic(kernel)
-        assert problem is None and traffic and src, (kernel, problem)
+    for kernel, run in (("w4_gemv", "llama2-7b-int4"), ("w4_gemv_dual", "llama2-7b-int4"), ("eng_token", "llama2-7b-int4-engine"),
+                        ("eng_token", "stablelm-3b-bf16")):
+        traffic, src, problem = bench.pmc_traffic(kernel, run)
+        assert problem is None and traffic and src, (kernel, run, problem)
     assert bench.pmc_traffic("no_such_kernel")[2] is not None
+    assert "no PMC summary of" in bench.pmc_traffic("w4_gemv", "no-such-run")[2]
