@@ -230,15 +230,17 @@ int parrot_argmax_advance(const void* logits, int V, int64_t* tokens, int32_t* p
 /* ---- stream engine: ONE launch per decode token ------------------------------------------------------------
  * The whole token (generate/base.py:131-153 for one iteration: embedding, every Block of lit_gpt/model.py:158-180,
  * ln_f, lm_head, greedy sampling) runs as one launch of 256 workgroups, one per CU (csrc/engine.hip).  In every
- * workgroup one LOADER wave streams that CU's share of every op's int4 weights - and of the K/V cache rows the CU
+ * workgroup one or two LOADER waves stream that CU's share of every op's weights - and of the K/V cache rows the CU
  * attends over - through a ring of LDS slots by LDS-DMA, in a fixed order that never waits for a data dependency, only
- * for a free slot; seven CONSUMER waves compute from LDS.  Activation vectors pass between CUs as 8-byte {data, tag}
+ * for a free slot; 15 or 14 CONSUMER waves compute from LDS.  Activation vectors pass between CUs as 8-byte {data, tag}
  * granules (tag = the step's epoch) written with write-through stores and polled with L1-bypassing loads: there is no
- * grid barrier.  Weights are kept in the "E4" layout: per 8 output rows (a block), per 1024 input
- * columns (a quad), four 1-KiB pieces in which lane l holds the 32-column slice of row l % 8 in quantisation group
- * 8 * quad + l / 8, plus one metadata piece per four quads; a CU owns a contiguous range of blocks of every Linear.
- * Supported: GPTQ int4 with group 128 and no bias, RMSNorm, sequential residual, SwiGLU MLP, head size 64 / 128,
- * q_per_kv 1 / 2 (the Llama-2 7B family); everything else keeps the multi-launch step.                               */
+ * grid barrier.  Weight layouts, both per 8 output rows (a block) and 1024 input columns (a unit):
+ *   E4  (GPTQ int4, group 128): four 1-KiB pieces in which lane l holds the 32-column slice of row l % 8 in quantisation
+ *       group 8 * unit + l / 8, plus one metadata piece per four units;
+ *   E16 (bf16): sixteen 1-KiB pieces, lane l of piece i holds columns 1024 unit + 64 i + 8 (l / 8) .. + 7 of row l % 8.
+ * A CU owns a contiguous range of blocks of every Linear.  Supported: every Linear int4 g128 without bias, or every
+ * Linear bf16 (bias allowed); RMSNorm or LayerNorm; SwiGLU or GELU MLP; sequential or parallel residual; head size
+ * 64 / 128, q_per_kv 1 / 2; inputs of up to 16384 elements.  Everything else keeps the multi-launch step.            */
 #define PARROT_ENG_GEMV 0
 #define PARROT_ENG_ATTN 1
 #define PARROT_ENG_EPI_LOGITS 4 /* lm_head: plain bf16 logits + the CU's arg-max candidate */
