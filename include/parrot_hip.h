@@ -297,13 +297,14 @@ typedef struct parrot_eng_state {
     const void* rope_cos;       /* fp16 [block_size][n_elem] */
     const void* rope_sin;
     int32_t n_elem, n_groups, q_per_kv, hs, S, V, rsqrt_mode;
-    int32_t nsplit;             /* CUs per query group in the attention op: min(8, 256 / n_groups) */
+    int32_t nsplit;             /* CUs per virtual group in the attention op: min(8, 256 / (n_groups * vper)) */
     int32_t greedy;             /* 1: tokens[pos + 1] = argmax(logits), pos += 1 inside the launch */
     int32_t lds_buf0_bytes, lds_buf1_bytes; /* from parrot_eng_lds_bytes */
     int32_t kmax;               /* the largest K of any op: above 11264 the build with a 6-slot ring runs */
     int32_t wfmt;               /* PARROT_ENG_W_*: the one weight format of every Linear of the launch */
     int32_t attn_buf;           /* which LDS buffer the attention ops use as scratch (must hold it) */
-    int32_t reserved;
+    int32_t vper;               /* virtual groups per K/V group: q_per_kv / vper = 1 or 2 query heads share one CU's pass over
+                                   the group's keys (GQA / MQA: every virtual group streams the K/V rows for its own heads) */
     uint64_t* arg;              /* 2 * 256 granules: every CU's arg-max candidate {value, index} */
     uint64_t* dbg;              /* NULL, or nops * 16 words: 100 MHz stamps of workgroup 0 (diagnostic runs only) */
     uint64_t* dbg_all;          /* NULL, or nops * 256 * 2 words: {input ready, units done} stamps of every workgroup */

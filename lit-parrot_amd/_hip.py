@@ -51,7 +51,7 @@ class EngState(C.Structure):  # parrot_eng_state_t
         [("ops", C.c_void_p), ("nops", C.c_int32), ("d", C.c_int32)]
         + [(n, C.c_void_p) for n in ("tokens", "pos", "epoch", "err", "wte", "rope_cos", "rope_sin")]
         + [(n, C.c_int32) for n in ("n_elem", "n_groups", "q_per_kv", "hs", "S", "V", "rsqrt_mode", "nsplit", "greedy",
-                                    "lds_buf0_bytes", "lds_buf1_bytes", "kmax", "wfmt", "attn_buf", "reserved")]
+                                    "lds_buf0_bytes", "lds_buf1_bytes", "kmax", "wfmt", "attn_buf", "vper")]
         + [(n, C.c_void_p) for n in ("arg", "dbg", "dbg_all")]
     )
 

@@ -139,6 +139,7 @@ _TABLE = [
     dict(_falcon("tiny-falcon-mqa", 2, 4, 128, 1, shared_attention_norm=True), org="test", block_size=128,
          vocab_size=512, padded_vocab_size=512),
     # Falcon-7B's odd shapes in small: width not a multiple of 128 (4544 = 71 x 64), an odd number of query heads on one K/V head
+    dict(_falcon("tiny-falcon-40b", 2, 8, 512, 2), org="test", block_size=128, vocab_size=512, padded_vocab_size=512),
     dict(_falcon("tiny-falcon-7b", 2, 7, 448, 1, shared_attention_norm=True), org="test", block_size=128,
          vocab_size=512, padded_vocab_size=512),
 ]

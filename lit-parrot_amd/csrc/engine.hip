@@ -313,7 +313,8 @@ __device__ __forceinline__ void eng_block_range(const EngOp* op, int cu, int& bs
 // key range of CU c in an attention op: group g, split s; keys [kb, ke) of the n_valid admitted slots
 struct EngKeys {
     bool part;  // this CU takes part in the attention op
-    int g, s, ns, kb, ke, nunits;  // group, split, splits in use at this position, key range, K/V units
+    int g, s, ns, kb, ke, nunits;  // (virtual) group, split, splits in use at this position, key range, K/V units
+    int gr, jv;                    // the K/V group the virtual group belongs to, and which of its st.vper parts it is
 };
 template <int HS>
 __device__ __forceinline__ EngKeys eng_keys(const EngState& st, int cu, int pos) {
@@ -328,7 +329,11 @@ __device__ __forceinline__ EngKeys eng_keys(const EngState& st, int cu, int pos)
     k.ns = ns;
     k.g = cu / st.nsplit;
     k.s = cu % st.nsplit;
-    k.part = cu < st.n_groups * st.nsplit && k.s < ns;
+    // A K/V group with more than 2 query heads is attended as st.vper VIRTUAL groups of 1 or 2 heads each (the kernel's HQ):
+    // every one of them streams the group's K/V rows for its own heads, so GQA / MQA models fill the 256 CUs too
+    k.gr = k.g / st.vper;
+    k.jv = k.g - k.gr * st.vper;
+    k.part = cu < st.n_groups * st.vper * st.nsplit && k.s < ns;
     int per = (n_valid + ns - 1) / ns;
     per = (per + KPP - 1) / KPP * KPP;
     k.kb = min(k.s * per, n_valid);
@@ -473,8 +478,8 @@ __device__ __forceinline__ void eng_loader(const EngState& st, const EngCtx& c, 
         } else if (op->epilogue != 2) {  // (the second half of a split attention op streams nothing)
             const EngKeys ky = eng_keys<HS>(st, c.cu, c.pos);
             const int64_t grp_bytes = (int64_t)st.S * HS * 2;
-            const unsigned char* kg = reinterpret_cast<const unsigned char*>(op->k_cache) + (int64_t)ky.g * grp_bytes;
-            const unsigned char* vg = reinterpret_cast<const unsigned char*>(op->v_cache) + (int64_t)ky.g * grp_bytes;
+            const unsigned char* kg = reinterpret_cast<const unsigned char*>(op->k_cache) + (int64_t)ky.gr * grp_bytes;
+            const unsigned char* vg = reinterpret_cast<const unsigned char*>(op->v_cache) + (int64_t)ky.gr * grp_bytes;
             for (int u0 = 0; u0 < ky.nunits; u0 += 8) {
                 if (!own()) {
                     ++seq;
@@ -894,18 +899,24 @@ __device__ __forceinline__ bool eng_attn_local(const EngState& st, const EngCtx&
 
     // ---- the group's rows of the QKV vector
     {
-        constexpr int NPAIR = (HQ + 2) * HS / 2, NLOAD = (NPAIR + 63) / 64;
-        const uint64_t* in = op->in + (int64_t)ky.g * NPAIR;
+        // rows of the K/V group in the QKV vector: q_per_kv query heads, k, v (model.py:204-213); this virtual group's are
+        // query heads jv * HQ .. + HQ - 1, then k, v
+        constexpr int NPAIR = (HQ + 2) * HS / 2, NLOAD = (NPAIR + 63) / 64, RP = HS / 2;
+        const uint64_t* in = op->in + (int64_t)ky.gr * (st.q_per_kv + 2) * RP;
+        auto src_pair = [&](int pr) {  // pair pr of the virtual group's rows -> its place in the K/V group's rows
+            const int rr = pr / RP;
+            return (rr < HQ ? ky.jv * HQ + rr : st.q_per_kv + (rr - HQ)) * RP + (pr - rr * RP);
+        };
         if (!ENG_ATTN_GATE) {
         } else if (w.cw == 0) {  // one poller per CU (see eng_gather)
-            (void)eng_gran_wait(st, c, in + (NPAIR - 1), 0, true, 0x52000000u | (uint32_t)k);
+            (void)eng_gran_wait(st, c, in + src_pair(NPAIR - 1), 0, true, 0x52000000u | (uint32_t)k);
             if (c.lane == 0) lds_st(c.fx + EF_GATE, (uint32_t)(k + 1));
         } else if (w.cw < NLOAD) {
             eng_wait_lds_ge(st, c, EF_GATE, (uint32_t)(k + 1), 0x53000000u | (uint32_t)k);
         }
         for (int t = w.cw; t < NLOAD; t += CF::NC) {
             const int pr = 64 * t + c.lane;
-            const uint64_t* p = in + min(pr, NPAIR - 1);
+            const uint64_t* p = in + src_pair(min(pr, NPAIR - 1));
             const uint32_t d = eng_gran_wait(st, c, p, ld_gran(p), pr < NPAIR, 0x50000000u | (uint32_t)k);
             if (pr < NPAIR) raw[pr] = d;
         }
@@ -964,8 +975,8 @@ __device__ __forceinline__ bool eng_attn_local(const EngState& st, const EngCtx&
         }
     }
     const int slot_new = c.pos % st.S;
-    if (w.cw == 0 && c.lane < LPR && slot_new >= ky.kb && slot_new < ky.ke) {  // KV append by the owner of the new slot
-        const int64_t off = ((int64_t)ky.g * st.S + slot_new) * HS + dl * 8;
+    if (w.cw == 0 && c.lane < LPR && ky.jv == 0 && slot_new >= ky.kb && slot_new < ky.ke) {  // KV append by the owner of the new slot
+        const int64_t off = ((int64_t)ky.gr * st.S + slot_new) * HS + dl * 8;
         typedef __attribute__((address_space(1))) u32x4_t* glb_u32x4_t;
         *(glb_u32x4_t)(reinterpret_cast<bf16_t*>(op->k_cache) + off) = u32x4_t{knew[0], knew[1], knew[2], knew[3]};
         *(glb_u32x4_t)(reinterpret_cast<bf16_t*>(op->v_cache) + off) = u32x4_t{vnew[0], vnew[1], vnew[2], vnew[3]};
@@ -1438,15 +1449,17 @@ int parrot_eng_step(const parrot_eng_state_t* state_host, void* stream) {
     PARROT_REQUIRE(st.ops && st.nops >= 1 && st.tokens && st.pos && st.epoch && st.err && st.wte && st.rope_cos && st.rope_sin && st.arg,
                    "eng_step: null pointer in state");
     PARROT_UNSUPPORTED(st.hs == 64 || st.hs == 128, "stream engine: head size %d not built (64, 128)", st.hs);
-    PARROT_UNSUPPORTED(st.q_per_kv == 1 || st.q_per_kv == 2, "stream engine: q_per_kv=%d not built (1, 2)", st.q_per_kv);
-    PARROT_REQUIRE(st.n_groups >= 1 && st.nsplit >= 1 && st.nsplit <= 8 && st.n_groups * st.nsplit <= ENG_WGS,
-                   "eng_step: n_groups * nsplit must fit the %d workgroups", ENG_WGS);
+    PARROT_REQUIRE(st.q_per_kv >= 1 && st.vper >= 1 && st.q_per_kv % st.vper == 0 && (st.q_per_kv / st.vper == 1 || st.q_per_kv / st.vper == 2),
+                   "eng_step: q_per_kv=%d must be vper=%d virtual groups of 1 or 2 query heads", st.q_per_kv, st.vper);
+    const int hq = st.q_per_kv / st.vper;
+    PARROT_REQUIRE(st.n_groups >= 1 && st.nsplit >= 1 && st.nsplit <= 8 && st.n_groups * st.vper * st.nsplit <= ENG_WGS,
+                   "eng_step: n_groups * vper * nsplit must fit the %d workgroups", ENG_WGS);
     PARROT_UNSUPPORTED(st.n_elem % 16 == 0 && st.n_elem >= 0 && st.n_elem <= st.hs && st.n_elem <= 128, "stream engine: rotary width %d must be a multiple of 16, at most the head size", st.n_elem);
     PARROT_REQUIRE(st.S >= 1 && st.V >= 1 && st.d >= 1, "eng_step: bad S / V / d");
     PARROT_REQUIRE(st.lds_buf0_bytes > 0 && st.lds_buf0_bytes % 16 == 0 && st.lds_buf1_bytes > 0 && st.lds_buf1_bytes % 16 == 0,
                    "eng_step: LDS buffer sizes must be positive multiples of 16");
     PARROT_REQUIRE(st.attn_buf == 0 || st.attn_buf == 1, "eng_step: attn_buf must be 0 or 1");
-    PARROT_REQUIRE((st.attn_buf ? st.lds_buf1_bytes : st.lds_buf0_bytes) >= eng_attn_scratch_bytes(st.hs, st.q_per_kv, st.nsplit),
+    PARROT_REQUIRE((st.attn_buf ? st.lds_buf1_bytes : st.lds_buf0_bytes) >= eng_attn_scratch_bytes(st.hs, hq, st.nsplit),
                    "eng_step: LDS buffer %d smaller than the attention scratch", st.attn_buf);
     PARROT_REQUIRE(st.kmax >= 1, "eng_step: kmax (the largest input of any op) must be set");
     {
@@ -1481,10 +1494,10 @@ int parrot_eng_step(const parrot_eng_state_t* state_host, void* stream) {
         PARROT_ENG_GO(HSV, HQV, 0, PARROT_ENG_W_E4);                  \
     } while (0)
     if (st.hs == 128) {
-        if (st.q_per_kv == 1) PARROT_ENG_GO2(128, 1);
+        if (hq == 1) PARROT_ENG_GO2(128, 1);
         PARROT_ENG_GO2(128, 2);
     }
-    if (st.q_per_kv == 1) PARROT_ENG_GO2(64, 1);
+    if (hq == 1) PARROT_ENG_GO2(64, 1);
     PARROT_ENG_GO2(64, 2);
 #undef PARROT_ENG_GO2
 #undef PARROT_ENG_GO

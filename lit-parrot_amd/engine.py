@@ -90,10 +90,10 @@ class StreamEngine:
                 return f"unsupported norm {type(n).__name__}"
         if not c.parallel_residual and c.shared_attention_norm:
             return "sequential residual with a shared attention norm"
-        if c.head_size not in (64, 128) or c.q_per_kv not in (1, 2):
-            return f"head size {c.head_size} / q_per_kv {c.q_per_kv}"
-        if c.n_query_groups > ENG_WGS or c.rope_n_elem % 16 or c.rope_n_elem > 128:
-            return "query group count / rotary width"
+        if c.head_size not in (64, 128):
+            return f"head size {c.head_size}"
+        if StreamEngine._attn_shape(c)[2] < 1 or c.rope_n_elem % 16 or c.rope_n_elem > 128:
+            return "more query-head pairs than CUs / rotary width"
         swiglu = c._mlp_class == "LLaMAMLP"
         if c.n_embd % 8 or c.qkv_size % 8 or c.padded_vocab_size % 8 or c.intermediate_size % (4 if swiglu else 8) or c.n_embd > 16384:
             return "row counts that do not fill the 8-row blocks"
@@ -107,17 +107,26 @@ class StreamEngine:
         return None
 
     @staticmethod
+    def _attn_shape(c):
+        """(query heads per virtual group, virtual groups per K/V group, CUs per virtual group).  The attention unit holds
+        1 or 2 query heads; a K/V group with more (GQA, MQA) is attended as several virtual groups, each streaming the
+        group's K/V rows for its own heads."""
+        hq = 2 if c.q_per_kv % 2 == 0 else 1
+        vper = c.q_per_kv // hq
+        return hq, vper, min(8, ENG_WGS // (c.n_query_groups * vper))
+
+    @staticmethod
     def _lds_buffers(c):
         """Bytes of the two LDS activation buffers and which one the attention ops use as scratch.  Buffer 0 holds the widest
         input (the MLP's hidden vector); sequential residual: the attention scratch too (the buffer is idle between the QKV
         Linear and the out-projection).  Parallel residual: the MLP's up-projection, whose input sits in buffer 0, runs
         around the attention ops, so their scratch goes to buffer 1."""
         lib = _hip.load()
-        nsplit = min(8, ENG_WGS // c.n_query_groups)
+        hq, _, nsplit = StreamEngine._attn_shape(c)
         kmax = max(c.intermediate_size, c.n_embd)
         if c.parallel_residual:
-            return lib.parrot_eng_lds_bytes(kmax, 0, 0, 0), lib.parrot_eng_lds_bytes(c.n_embd, c.head_size, c.q_per_kv, nsplit), 1
-        return lib.parrot_eng_lds_bytes(kmax, c.head_size, c.q_per_kv, nsplit), lib.parrot_eng_lds_bytes(c.n_embd, 0, 0, 0), 0
+            return lib.parrot_eng_lds_bytes(kmax, 0, 0, 0), lib.parrot_eng_lds_bytes(c.n_embd, c.head_size, hq, nsplit), 1
+        return lib.parrot_eng_lds_bytes(kmax, c.head_size, hq, nsplit), lib.parrot_eng_lds_bytes(c.n_embd, 0, 0, 0), 0
 
     @staticmethod
     def faster_than_multi_launch(model, window: int, int4_min_window: int) -> bool:
@@ -135,7 +144,7 @@ class StreamEngine:
         c = model.config
         dev = tokens.device
         L, d, hs, inter, V = c.n_layer, c.n_embd, c.head_size, c.intermediate_size, c.padded_vocab_size
-        nsplit = min(8, ENG_WGS // c.n_query_groups)
+        _, vper, nsplit = self._attn_shape(c)
         swiglu = c._mlp_class == "LLaMAMLP"
         attn_buf = self._lds_buffers(c)[2]
         self.logits = torch.zeros((1, V), dtype=torch.bfloat16, device=dev)
@@ -247,6 +256,7 @@ class StreamEngine:
         st.rope_cos, st.rope_sin = ptr(cos), ptr(sin)
         st.n_elem, st.n_groups, st.q_per_kv, st.hs, st.S = c.rope_n_elem, c.n_query_groups, c.q_per_kv, hs, S
         st.V, st.rsqrt_mode, st.nsplit, st.greedy = V, ops.RMSNORM_RSQRT_MODE, nsplit, int(greedy)
+        st.vper = vper
         st.kmax = max(inter, d)
         st.wfmt = ops_list[0].wfmt
         st.lds_buf0_bytes, st.lds_buf1_bytes, st.attn_buf = self._lds_buffers(c)

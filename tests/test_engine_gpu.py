@@ -194,7 +194,7 @@ def assert_same_step(log_a, log_b, tok_a, tok_b, T):
         assert float(log_a[i].max() - log_a[i][t]) <= 2 ** -5 * scale, (i, t)
 
 
-@pytest.mark.parametrize("name", ["tiny-llama", "tiny-llama-hs128", "tiny-llama-gqa"])
+@pytest.mark.parametrize("name", ["tiny-llama", "tiny-llama-hs128", "tiny-llama-gqa", "tiny-falcon-40b"])
 def test_engine_step_equals_the_multi_launch_step(name):
     cfg, qsd, model = int4_model(name)
     assert StreamEngine.supported(model) is None
@@ -219,11 +219,12 @@ def test_engine_step_equals_the_multi_launch_step(name):
             assert float(d.max()) <= 1.5e-2 * max(1.0, float(ref.abs().max())) and float(d.mean()) <= 3e-3
 
 
-@pytest.mark.parametrize("name", ["tiny-neox-hs64", "tiny-neox-hs128", "tiny-llama", "tiny-llama-gqa"])
+@pytest.mark.parametrize("name", ["tiny-neox-hs64", "tiny-neox-hs128", "tiny-llama", "tiny-llama-gqa", "tiny-falcon-40b", "tiny-falcon-7b"])
 def test_engine_step_on_bf16_weights_equals_the_multi_launch_step(name):
     """bf16 Linears (E16 layout) - with LayerNorm + bias, GELU, biases on every Linear, a partial rotary width and the
-    parallel residual of the NeoX family (model.py:166-171), or with the Llama block - against the multi-launch step on the
-    same forced tokens, run to run, and against the oracle."""
+    parallel residual of the NeoX family (model.py:166-171), with the Llama block, or with Falcon's grouped / multi-query
+    attention (4 query heads per K/V head as two virtual groups of 2; 7 on one K/V head as seven of 1; shared attention norm) -
+    against the multi-launch step on the same forced tokens, run to run, and against the oracle."""
     cfg, sd, model = bf16_model(name)
     assert StreamEngine.supported(model) is None
     prompt = synthetic_prompt(cfg, 9, 3)
