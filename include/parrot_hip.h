@@ -270,7 +270,9 @@ typedef struct parrot_eng_op {
                               (norm2_w); ATTN 1: barrier first (the scratch buffer's last readers may still be at work) */
     int32_t blk_part;      /* GEMV: this op covers part blk_part of blk_parts of every CU's blocks of the Linear */
     int32_t blk_parts;     /*       (0 or 1: all of them); not with PARROT_EPI_RESIDUAL */
-    int32_t reserved;
+    int32_t acc;           /* GEMV over one K-chunk of a Linear whose input does not fit LDS: 0 the whole Linear; 1 first chunk
+                              (the rows' sums are kept in the CU), 2 a middle chunk (added), 3 the last chunk (added, then
+                              the epilogue).  W / in / K describe the chunk; needs nq < 11 (16 in the wide build) */
     const void* W;         /* E4 / E16 weights */
     const void* norm_w;    /* K bf16 */
     const void* norm_b;    /* K bf16 or NULL (LayerNorm) */

@@ -41,7 +41,7 @@ class EngOp(C.Structure):  # parrot_eng_op_t
     _fields_ = (
         [(n, C.c_int32) for n in ("type", "epilogue", "K", "nblocks", "nq", "buf", "norm_kind")]
         + [("norm_eps", C.c_float)]
-        + [(n, C.c_int32) for n in ("in_embedding", "res_embedding", "wfmt", "res_in", "res_out", "publish", "no_gather", "blk_part", "blk_parts", "reserved")]
+        + [(n, C.c_int32) for n in ("in_embedding", "res_embedding", "wfmt", "res_in", "res_out", "publish", "no_gather", "blk_part", "blk_parts", "acc")]
         + [(n, C.c_void_p) for n in ("W", "norm_w", "norm_b", "bias", "norm2_w", "norm2_b", "inp", "out", "part", "k_cache", "v_cache")]
     )
 

@@ -411,23 +411,28 @@ __device__ __forceinline__ void eng_loader(const EngState& st, const EngCtx& c, 
                 // them sat in front of the hand-off polls (vmcnt is in order) with an HBM miss of 1 - 2 us; every consumer
                 // wave reads its share
                 // (a second norm of the same input - the MLP's of a parallel-residual block - follows in a slot of its own)
+                // (weight and bias share a slot when both fit - K <= 4096 - else they take one each)
+                const int npw = (op->K * 2 + 1023) >> 10;
+                const int64_t last = (int64_t)op->K * 2 - 16;
                 for (int which = 0; which < (op->norm2_w != nullptr ? 2 : 1); ++which) {
-                    if (!own()) {
-                        ++seq;
-                        continue;
-                    }
                     const unsigned char* nw = reinterpret_cast<const unsigned char*>(which ? op->norm2_w : op->norm_w);
                     const unsigned char* nb = reinterpret_cast<const unsigned char*>(which ? op->norm2_b : op->norm_b);
-                    const int npw = (op->K * 2 + 1023) >> 10;
-                    const int np = nb != nullptr ? 2 * npw : npw;
-                    const uint32_t target = acquire(np, k);
-                    const unsigned dst = __builtin_amdgcn_readfirstlane(ring_lds + (unsigned)((seq % NSLOT) * ENG_SLOT_BYTES));
-                    const int64_t last = (int64_t)op->K * 2 - 16;
-                    for (int j = 0; j < npw; ++j) eng_dma<false>(nw + min((int64_t)j * 1024 + c.lane * 16, last), dst + (unsigned)(j * 1024));
-                    if (nb != nullptr)
-                        for (int j = 0; j < npw; ++j)
-                            eng_dma<false>(nb + min((int64_t)j * 1024 + c.lane * 16, last), dst + (unsigned)((npw + j) * 1024));
-                    commit(target, np, CF::NC);
+                    const bool split = nb != nullptr && 2 * npw > 16;
+                    for (int half = 0; half < (split ? 2 : 1); ++half) {
+                        if (!own()) {
+                            ++seq;
+                            continue;
+                        }
+                        const int np = (nb != nullptr && !split) ? 2 * npw : npw;
+                        const uint32_t target = acquire(np, k);
+                        const unsigned dst = __builtin_amdgcn_readfirstlane(ring_lds + (unsigned)((seq % NSLOT) * ENG_SLOT_BYTES));
+                        const unsigned char* first = half ? nb : nw;
+                        for (int j = 0; j < npw; ++j) eng_dma<false>(first + min((int64_t)j * 1024 + c.lane * 16, last), dst + (unsigned)(j * 1024));
+                        if (nb != nullptr && !split)
+                            for (int j = 0; j < npw; ++j)
+                                eng_dma<false>(nb + min((int64_t)j * 1024 + c.lane * 16, last), dst + (unsigned)((npw + j) * 1024));
+                        commit(target, np, CF::NC);
+                    }
                 }
             }
             int bs, nb, bstep;
@@ -685,10 +690,17 @@ __device__ __forceinline__ void eng_gather(const EngState& st, const EngCtx& c0,
     const int nb_off = ((K * 2 + 1023) >> 10) << 10;  // LayerNorm bias behind the weights
     auto round = [&](bool second) {
         const unsigned char* nslot = c.ring;
+        const unsigned char* bslot = c.ring;
         const bool has_nb = na.kind == 2 && (second ? op->norm2_b : op->norm_b) != nullptr;
-        if (na.kind != 0) {  // the norm weights arrived through the ring (one slot, in front of the op's weights)
+        const bool split = has_nb && 2 * nb_off > 16 * 1024;  // weight and bias in a slot each (K > 4096)
+        if (na.kind != 0) {  // the norm weights arrived through the ring (in front of the op's weights)
             eng_wait_full<CF>(st, c, w, w.seq);
             nslot = c.ring + (w.seq % CF::NSLOT) * ENG_SLOT_BYTES;
+            bslot = nslot + nb_off;
+            if (split) {
+                eng_wait_full<CF>(st, c, w, w.seq + 1);
+                bslot = c.ring + ((w.seq + 1) % CF::NSLOT) * ENG_SLOT_BYTES;
+            }
             eng_stamp(st, c, w, k, 10);
         }
         const bool to1 = (op->buf != 0) != second;
@@ -705,7 +717,7 @@ __device__ __forceinline__ void eng_gather(const EngState& st, const EngCtx& c0,
                     if (na.kind != 0) {
                         const uint32_t nwp = *reinterpret_cast<const uint32_t*>(nslot + min(pr, npairs - 1) * 4);
                         uint32_t nbp = 0u;
-                        if (has_nb) nbp = *reinterpret_cast<const uint32_t*>(nslot + nb_off + min(pr, npairs - 1) * 4);
+                        if (has_nb) nbp = *reinterpret_cast<const uint32_t*>(bslot + min(pr, npairs - 1) * 4);
                         o = pr < npairs ? norm_apply(o, nwp, nbp, na.kind, mean, r) : 0u;
                     }
                 }
@@ -719,7 +731,8 @@ __device__ __forceinline__ void eng_gather(const EngState& st, const EngCtx& c0,
         eng_stamp(st, c, w, k, 11);
         if (na.kind != 0) {
             eng_release<CF>(c, w.seq);
-            w.seq += 1;
+            if (split) eng_release<CF>(c, w.seq + 1);
+            w.seq += split ? 2 : 1;
         }
     };
     round(false);
@@ -826,6 +839,18 @@ __device__ __forceinline__ void eng_gemv(const EngState& st, const EngCtx& c0, E
             lds_st(c.fx + EF_DONE + rb * 4, 0u);
             float a = 0.f;
             for (int q = 0; q < nq; ++q) a += red[(rb * MAXQ + q) * 8 + r];
+            if (op->acc != 0) {
+                // this op is one K-chunk of a Linear whose input does not fit LDS (Falcon-40B's down-projection, K = 32768):
+                // the chunks' sums meet in a per-row accumulator - the result slot of unit MAXQ - 1, which a chunk (nq <
+                // MAXQ, checked on the host) never fills - in chunk order; the last chunk goes on to the epilogue
+                const int lr = (bl * 8 + r) & 63;
+                float* ca = red + (((lr >> 3) * MAXQ + (MAXQ - 1)) * 8 + (lr & 7));
+                if (op->acc >= 2) a += *ca;
+                if (op->acc <= 2) {
+                    if (c.lane < 8) *ca = a;
+                    goto unit_done;
+                }
+            }
             if (has_bias) a += redb[rb * 8 + r];
             float o = rbf(a);
             if (epi == PARROT_EPI_RESIDUAL) {
@@ -858,6 +883,7 @@ __device__ __forceinline__ void eng_gemv(const EngState& st, const EngCtx& c0, E
                     st_gran(reinterpret_cast<uint64_t*>(op->out) + ((b * rows + c.lane) >> 1), ob | (nb << 16), c.epoch);
             }
         }
+    unit_done:
         bl += step_b;
         Q += step_q;
         if (Q >= nq) {
@@ -1431,14 +1457,25 @@ int64_t parrot_eng_lds_bytes(int K, int hs, int q_per_kv, int nsplit) {
     return (b + 15) / 16 * 16;
 }
 
+// which build runs (wide = 6 ring slots, inputs up to 16384) and its dynamic LDS: the narrow one when the inputs allow it and
+// it fits the CU
+static int64_t eng_pick_build(int kmax, int wfmt, int buf0_bytes, int buf1_bytes, bool* big) {
+    const bool e16 = wfmt == PARROT_ENG_W_E16;
+    int64_t lds = 0;
+    for (int b = eng_is_big(kmax) ? 1 : 0; b < 2; ++b) {
+        const int nslot = e16 ? (b ? EngCfg<1, PARROT_ENG_W_E16>::NSLOT : EngCfg<0, PARROT_ENG_W_E16>::NSLOT) : (b ? ENG_NSLOT_BIG : ENG_NSLOT_STD);
+        lds = (int64_t)nslot * ENG_SLOT_BYTES + buf0_bytes + buf1_bytes + EF_RED + ENG_RED * (b ? ENG_MAXQ_BIG : ENG_MAXQ_STD) * 32;
+        *big = b != 0;
+        if (lds <= 160 * 1024) break;
+    }
+    return lds;
+}
+
 int64_t parrot_eng_lds_total(int kmax, int wfmt, int buf0_bytes, int buf1_bytes) {
     PARROT_REQUIRE(kmax > 0 && buf0_bytes > 0 && buf1_bytes > 0, "eng_lds_total: sizes must be positive");
     PARROT_REQUIRE(wfmt == PARROT_ENG_W_E4 || wfmt == PARROT_ENG_W_E16, "eng_lds_total: unknown weight format %d", wfmt);
-    const bool big = eng_is_big(kmax);
-    const int nslot = wfmt == PARROT_ENG_W_E16 ? (big ? EngCfg<1, PARROT_ENG_W_E16>::NSLOT : EngCfg<0, PARROT_ENG_W_E16>::NSLOT)
-                                               : (big ? ENG_NSLOT_BIG : ENG_NSLOT_STD);
-    const int64_t lds = (int64_t)nslot * ENG_SLOT_BYTES + buf0_bytes + buf1_bytes +
-                        (big ? EF_RED + ENG_RED * ENG_MAXQ_BIG * 32 : EF_RED + ENG_RED * ENG_MAXQ_STD * 32);
+    bool big;
+    const int64_t lds = eng_pick_build(kmax, wfmt, buf0_bytes, buf1_bytes, &big);
     PARROT_UNSUPPORTED(lds <= 160 * 1024, "stream engine: needs %lld B of LDS", (long long)lds);
     return lds;
 }
@@ -1471,7 +1508,8 @@ int parrot_eng_step(const parrot_eng_state_t* state_host, void* stream) {
     const int64_t lds_total = parrot_eng_lds_total(st.kmax, st.wfmt, st.lds_buf0_bytes, st.lds_buf1_bytes);
     if (lds_total < 0) return (int)lds_total;
     const size_t lds = (size_t)lds_total;
-    const bool big = eng_is_big(st.kmax);
+    bool big;
+    (void)eng_pick_build(st.kmax, st.wfmt, st.lds_buf0_bytes, st.lds_buf1_bytes, &big);
     PARROT_REQUIRE(st.wfmt == PARROT_ENG_W_E4 || st.wfmt == PARROT_ENG_W_E16, "eng_step: unknown weight format %d", st.wfmt);
     const bool e16 = st.wfmt == PARROT_ENG_W_E16;
     hipStream_t s = (hipStream_t)stream;

@@ -18,44 +18,53 @@ from .quantize.gptq import ColBlockQuantizedLinear
 from .rmsnorm import RMSNorm
 
 
-def e4_image(lin: ColBlockQuantizedLinear, partner: Optional[ColBlockQuantizedLinear] = None) -> torch.Tensor:
-    """E4 copy of an int4 Linear (of the SwiGLU pair ``lin`` = fc_1, ``partner`` = fc_2), built by the repack kernel
-    from the reference-format buffers the module keeps (quantize/gptq.py:216-231)."""
+def e4_image(lin: ColBlockQuantizedLinear, partner: Optional[ColBlockQuantizedLinear] = None, k0: int = 0,
+             k1: Optional[int] = None) -> torch.Tensor:
+    """E4 copy of an int4 Linear (of the SwiGLU pair ``lin`` = fc_1, ``partner`` = fc_2; of its input columns
+    [k0, k1): one K-chunk), built by the repack kernel from the reference-format buffers the module keeps
+    (quantize/gptq.py:216-231)."""
     lib = _hip.load()
     N, K = lin.out_features, lin.in_features
-    nbytes = lib.parrot_e4_bytes(N, K, int(partner is not None))
+    k1 = K if k1 is None else k1
+    if k0 % 128 or (k1 % 128 and k1 != K) or not 0 <= k0 < k1 <= K:
+        raise ParrotHipError(f"e4_image: the chunk [{k0}, {k1}) must start and end on quantisation groups")
+    nbytes = lib.parrot_e4_bytes(N, k1 - k0, int(partner is not None))
     if nbytes < 0:
         raise ParrotHipError(f"parrot_e4_bytes failed ({nbytes}): {_hip.last_error()}")
     out = torch.empty((nbytes,), dtype=torch.uint8, device=lin.quant_weight.device)
     keep = []
 
     def bufs(m):
-        s = m.scales.to(torch.bfloat16).contiguous()
-        z = m.zeros.to(torch.bfloat16).contiguous()
-        keep.extend((s, z))
         if m.quant_weight.stride() != (1, m.out_features):
             raise ParrotHipError("ColBlockQuantizedLinear.quant_weight lost its column-major layout")
-        return ptr(m.quant_weight), ptr(s), ptr(z)
+        g0, g1 = k0 // 128, -(-k1 // 128)
+        s = m.scales[:, g0:g1].to(torch.bfloat16).contiguous()
+        z = m.zeros[:, g0:g1].to(torch.bfloat16).contiguous()
+        q = m.quant_weight[:, k0 // 2:k1 // 2]  # storage rows k0/2 .. k1/2 of the (K/2, N) array: contiguous
+        keep.extend((s, z, q))
+        return ptr(q), ptr(s), ptr(z)
 
     q1, s1, z1 = bufs(lin)
     q2, s2, z2 = bufs(partner) if partner is not None else (None, None, None)
-    check(lib.parrot_e4_repack(q1, s1, z1, q2, s2, z2, N, K, ptr(out), _hip.stream()), "parrot_e4_repack")
+    check(lib.parrot_e4_repack(q1, s1, z1, q2, s2, z2, N, k1 - k0, ptr(out), _hip.stream()), "parrot_e4_repack")
     return out
 
 
-def e16_image(lin: torch.nn.Linear, partner: Optional[torch.nn.Linear] = None) -> torch.Tensor:
-    """E16 copy of a bf16 ``nn.Linear`` weight (of the SwiGLU pair): per 8 rows and 1024 columns one 16-KiB ring slot."""
+def e16_image(lin: torch.nn.Linear, partner: Optional[torch.nn.Linear] = None, k0: int = 0, k1: Optional[int] = None) -> torch.Tensor:
+    """E16 copy of a bf16 ``nn.Linear`` weight (of the SwiGLU pair; of its input columns [k0, k1)): per 8 rows and 1024
+    columns one 16-KiB ring slot."""
     lib = _hip.load()
     N, K = lin.out_features, lin.in_features
-    nbytes = lib.parrot_e16_bytes(N, K, int(partner is not None))
+    k1 = K if k1 is None else k1
+    nbytes = lib.parrot_e16_bytes(N, k1 - k0, int(partner is not None))
     if nbytes < 0:
         raise ParrotHipError(f"parrot_e16_bytes failed ({nbytes}): {_hip.last_error()}")
-    w1 = lin.weight.data.contiguous()
-    w2 = partner.weight.data.contiguous() if partner is not None else None
+    w1 = lin.weight.data[:, k0:k1].contiguous()
+    w2 = partner.weight.data[:, k0:k1].contiguous() if partner is not None else None
     if w1.dtype != torch.bfloat16 or (w2 is not None and w2.dtype != torch.bfloat16):
         raise ParrotHipError("e16_image: the weights must be bf16")
     out = torch.empty((nbytes,), dtype=torch.uint8, device=w1.device)
-    check(lib.parrot_e16_repack(ptr(w1), ptr(w2) if w2 is not None else None, N, K, ptr(out), _hip.stream()), "parrot_e16_repack")
+    check(lib.parrot_e16_repack(ptr(w1), ptr(w2) if w2 is not None else None, N, k1 - k0, ptr(out), _hip.stream()), "parrot_e16_repack")
     return out
 
 
@@ -80,14 +89,10 @@ class StreamEngine:
             return "the Linears are neither all int4 GPTQ nor all plain bf16"
         norms = [model.transformer.ln_f] + [n for b in model.transformer.h for n in (b.norm_1, getattr(b, "norm_2", None)) if n is not None]
         for n in norms:
-            if isinstance(n, RMSNorm):
-                if c.n_embd > 8192:
-                    return "norm weights beyond one ring slot"
-            elif isinstance(n, torch.nn.LayerNorm):
-                if c.n_embd > (4096 if n.bias is not None else 8192):
-                    return "norm weights and bias beyond one ring slot"
-            else:
+            if not isinstance(n, (RMSNorm, torch.nn.LayerNorm)):
                 return f"unsupported norm {type(n).__name__}"
+        if c.n_embd > 8192:
+            return "norm weights beyond one ring slot"
         if not c.parallel_residual and c.shared_attention_norm:
             return "sequential residual with a shared attention norm"
         if c.head_size not in (64, 128):
@@ -102,8 +107,13 @@ class StreamEngine:
             return f"the engine keeps {ENG_WGS} workgroups resident, one per CU: the device has fewer CUs"
         wfmt = ENG_W_E4 if isinstance(linears[0], ColBlockQuantizedLinear) else ENG_W_E16
         b0, b1, _ = StreamEngine._lds_buffers(c)
-        if b0 < 0 or b1 < 0 or _hip.load().parrot_eng_lds_total(max(c.intermediate_size, c.n_embd), wfmt, b0, b1) < 0:
+        kmax = max([c.n_embd] + [k1 - k0 for k0, k1 in StreamEngine._down_chunks(c)])
+        if b0 < 0 or b1 < 0 or _hip.load().parrot_eng_lds_total(kmax, wfmt, b0, b1) < 0:
             return _hip.last_error()
+        if wfmt == ENG_W_E4 and StreamEngine.CHUNK % 128:
+            return "the K-chunks of an int4 down-projection must start on quantisation groups"
+        if (c.n_embd // 8 + ENG_WGS - 1) // ENG_WGS > 8:
+            return "more than 64 residual rows per CU"
         return None
 
     @staticmethod
@@ -115,18 +125,32 @@ class StreamEngine:
         vper = c.q_per_kv // hq
         return hq, vper, min(8, ENG_WGS // (c.n_query_groups * vper))
 
+    CHUNK_ABOVE = 16384  # the widest input an LDS activation buffer holds beside the ring
+    CHUNK = 8192         # input columns per K-chunk of a down-projection wider than that
+
+    @staticmethod
+    def _down_chunks(c):
+        """[k0, k1) ranges of the MLP down-projection's input: one range, or chunks when it does not fit LDS."""
+        K = c.intermediate_size
+        if K <= StreamEngine.CHUNK_ABOVE:
+            return [(0, K)]
+        return [(k, min(k + StreamEngine.CHUNK, K)) for k in range(0, K, StreamEngine.CHUNK)]
+
     @staticmethod
     def _lds_buffers(c):
-        """Bytes of the two LDS activation buffers and which one the attention ops use as scratch.  Buffer 0 holds the widest
-        input (the MLP's hidden vector); sequential residual: the attention scratch too (the buffer is idle between the QKV
-        Linear and the out-projection).  Parallel residual: the MLP's up-projection, whose input sits in buffer 0, runs
-        around the attention ops, so their scratch goes to buffer 1."""
+        """Bytes of the two LDS activation buffers and which one the attention ops use as scratch.  Consecutive Linears
+        alternate between the buffers.  Sequential residual: QKV 1, out-projection 0, MLP up 1, down-projection (chunks) 0,
+        1, ...; the attention scratch shares buffer 0 (idle between the QKV Linear and the out-projection).  Parallel
+        residual: QKV 1, MLP up 0 - its thirds run around the attention ops, so their scratch goes to buffer 1 -
+        out-projection 1, down-projection (chunks) 0, 1, ..."""
         lib = _hip.load()
         hq, _, nsplit = StreamEngine._attn_shape(c)
-        kmax = max(c.intermediate_size, c.n_embd)
-        if c.parallel_residual:
-            return lib.parrot_eng_lds_bytes(kmax, 0, 0, 0), lib.parrot_eng_lds_bytes(c.n_embd, c.head_size, hq, nsplit), 1
-        return lib.parrot_eng_lds_bytes(kmax, c.head_size, hq, nsplit), lib.parrot_eng_lds_bytes(c.n_embd, 0, 0, 0), 0
+        k = [c.n_embd, c.n_embd]
+        for i, (k0, k1) in enumerate(StreamEngine._down_chunks(c)):
+            k[i & 1] = max(k[i & 1], k1 - k0)
+        ab = 1 if c.parallel_residual else 0
+        sizes = [lib.parrot_eng_lds_bytes(k[b], *((c.head_size, hq, nsplit) if b == ab else (0, 0, 0))) for b in (0, 1)]
+        return sizes[0], sizes[1], ab
 
     @staticmethod
     def faster_than_multi_launch(model, window: int, int4_min_window: int) -> bool:
@@ -167,12 +191,27 @@ class StreamEngine:
         ops_list: List[EngOp] = []
 
         images = {}
+        self.kmax = 0
+        chunks = self._down_chunks(c)
+
+        def down(i: int, res_in: int) -> None:
+            """The MLP down-projection of block i: one op, or one per K-chunk with the rows' sums accumulated in the CU."""
+            mlp = model.transformer.h[i].mlp
+            for j, (k0, k1) in enumerate(chunks):
+                last = j == len(chunks) - 1
+                acc = 0 if len(chunks) == 1 else (1 if j == 0 else (3 if last else 2))
+                gemv(mlp.proj, d // 8, EPI_RESIDUAL if last else EPI_NONE, j & 1, gran(i, "h") + 8 * (k0 // 2), gran(i, "xb") if last else None,
+                     res_in=res_in, res_out=0, publish=last, cols=(k0, k1), acc=acc)
 
         def gemv(lin, nblocks: int, epilogue: int, buf: int, inp: Optional[int], out: Optional[int], *, partner=None, norm=None,
-                 norm2=None, no_gather=False, in_emb=False, res_emb=False, res_in=0, res_out=0, publish=True, part=(0, 1)) -> None:
+                 norm2=None, no_gather=False, in_emb=False, res_emb=False, res_in=0, res_out=0, publish=True, part=(0, 1),
+                 cols=None, acc=0) -> None:
             op = EngOp()
-            K = lin.in_features
+            k0, k1 = cols if cols is not None else (0, lin.in_features)
+            K = k1 - k0
             op.type, op.epilogue, op.K, op.nblocks, op.nq, op.buf = ENG_GEMV, epilogue, K, nblocks, (K + 1023) // 1024, buf
+            op.acc = acc
+            self.kmax = max(self.kmax, K)
             op.blk_part, op.blk_parts = part
             if part[1] > 1 and epilogue == EPI_RESIDUAL:
                 raise ParrotHipError("stream engine: a Linear with a residual epilogue is not split into parts")
@@ -182,9 +221,9 @@ class StreamEngine:
                 if partner is not None:
                     raise ParrotHipError("stream engine: a SwiGLU pair with biases is not built")
                 op.bias = ptr(lin.bias.data)
-            img = images.get(id(lin))
+            img = images.get((id(lin), k0, k1))
             if img is None:
-                img = images[id(lin)] = e4_image(lin, partner) if e4 else e16_image(lin, partner)
+                img = images[(id(lin), k0, k1)] = e4_image(lin, partner, k0, k1) if e4 else e16_image(lin, partner, k0, k1)
                 self.images.append(img)
             op.W, op.inp, op.out = img.data_ptr(), inp, out
             if norm is not None:
@@ -234,13 +273,13 @@ class StreamEngine:
                 ops_list.append(at2)
                 gemv(up, up_blocks, up_epi, 0, None, gran(i, "h"), partner=partner, no_gather=True, part=(2, 3))
                 gemv(block.attn.proj, d // 8, EPI_RESIDUAL, 1, gran(i, "y"), None, res_emb=first, res_in=0, res_out=1, publish=False)
-                gemv(mlp.proj, d // 8, EPI_RESIDUAL, 0, gran(i, "h"), gran(i, "xb"), res_in=1, res_out=0)
+                down(i, 1)
             else:
                 at.buf = attn_buf
                 ops_list.append(at)
                 gemv(block.attn.proj, d // 8, EPI_RESIDUAL, 0, gran(i, "y"), gran(i, "xa"), res_emb=first)
                 gemv(up, up_blocks, up_epi, 1, gran(i, "xa"), gran(i, "h"), partner=partner, norm=block.norm_2)
-                gemv(mlp.proj, d // 8, EPI_RESIDUAL, 0, gran(i, "h"), gran(i, "xb"))
+                down(i, 0)
         gemv(model.lm_head, V // 8, ENG_EPI_LOGITS, 1, gran(L - 1, "xb"), ptr(self.logits), norm=model.transformer.ln_f)
 
         arr = (EngOp * len(ops_list))(*ops_list)
@@ -257,7 +296,7 @@ class StreamEngine:
         st.n_elem, st.n_groups, st.q_per_kv, st.hs, st.S = c.rope_n_elem, c.n_query_groups, c.q_per_kv, hs, S
         st.V, st.rsqrt_mode, st.nsplit, st.greedy = V, ops.RMSNORM_RSQRT_MODE, nsplit, int(greedy)
         st.vper = vper
-        st.kmax = max(inter, d)
+        st.kmax = self.kmax
         st.wfmt = ops_list[0].wfmt
         st.lds_buf0_bytes, st.lds_buf1_bytes, st.attn_buf = self._lds_buffers(c)
         st.arg = self.granules.data_ptr() + 8 * L * per_layer

@@ -248,6 +248,24 @@ def test_engine_step_on_bf16_weights_equals_the_multi_launch_step(name):
             assert float(d.max()) <= 2 ** -5 * scale and float(d.mean()) <= 2e-3 * scale, (i, float(d.max()), float(d.mean()))
 
 
+@pytest.mark.parametrize("name,quant", [("tiny-falcon-40b", False), ("tiny-falcon-40b", True), ("tiny-llama", True), ("tiny-neox-hs64", False)])
+def test_engine_k_chunked_down_projection(name, quant, monkeypatch):
+    """A down-projection whose input does not fit LDS (Falcon-40B: 32768 columns) runs as one op per K-chunk, the rows' sums
+    accumulated in the CU in chunk order: forced here on small models (chunks of 256 / 128 columns, ragged last chunk),
+    against the multi-launch step on the same tokens."""
+    monkeypatch.setattr(StreamEngine, "CHUNK_ABOVE", 256)
+    monkeypatch.setattr(StreamEngine, "CHUNK", 128 if name == "tiny-llama" else 256)
+    cfg, _, model = int4_model(name) if quant else bf16_model(name)
+    assert len(StreamEngine._down_chunks(cfg)) >= 3 and StreamEngine.supported(model) is None
+    prompt = synthetic_prompt(cfg, 9, 3)
+    tok_a, log_a = run_session(model, prompt, 20, engine=False)
+    tok_b, log_b = run_session(model, prompt, 20, engine=True, follow=tok_a.to(DEV))
+    assert_same_step(log_a, log_b, tok_a, tok_b, 9)
+    tok_c, log_c = run_session(model, prompt, 20, engine=True)
+    tok_d, log_d = run_session(model, prompt, 20, engine=True, use_graph=False)
+    assert torch.equal(tok_c, tok_d) and torch.equal(log_c, log_d)
+
+
 def test_engine_ring_window_and_generate(monkeypatch):
     """generate() end to end on the engine, with a window smaller than the sequence (ring slots) and sampling."""
     cfg, qsd, model = int4_model("tiny-llama")
