@@ -240,7 +240,8 @@ int parrot_argmax_advance(const void* logits, int V, int64_t* tokens, int32_t* p
  *   E16 (bf16): sixteen 1-KiB pieces, lane l of piece i holds columns 1024 unit + 64 i + 8 (l / 8) .. + 7 of row l % 8.
  * A CU owns a contiguous range of blocks of every Linear.  Supported: every Linear int4 g128 without bias, or every
  * Linear bf16 (bias allowed); RMSNorm or LayerNorm; SwiGLU or GELU MLP; sequential or parallel residual; head size
- * 64 / 128, q_per_kv 1 / 2; inputs of up to 16384 elements.  Everything else keeps the multi-launch step.            */
+ * 64 / 128, any q_per_kv (virtual groups of 1 or 2 query heads, `vper`); n_embd up to 8192; inputs of up to 16384
+ * elements per op (wider Linears as K-chunk ops, `acc`).  Everything else keeps the multi-launch step.               */
 #define PARROT_ENG_GEMV 0
 #define PARROT_ENG_ATTN 1
 #define PARROT_ENG_EPI_LOGITS 4 /* lm_head: plain bf16 logits + the CU's arg-max candidate */

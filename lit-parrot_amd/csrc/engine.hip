@@ -376,15 +376,17 @@ __device__ __forceinline__ void eng_loader(const EngState& st, const EngCtx& c, 
     auto acquire = [&](int np, int k) -> uint32_t {
         const int r = seq % NSLOT;
         const uint32_t target = (uint32_t)__builtin_amdgcn_readlane(exp_v, r);
-        if (lds_ld(c.fx + EF_CONS + r * 4) != target) {
-            while (pub < mine) publish_oldest();  // never sleep on a free slot with landed data unannounced
+        // (one publish loop for the three reasons to announce older slots first - the vmcnt switch inside is 64 cases of
+        // code per copy and the kernel's text is felt: never sleep on a busy slot with landed data unannounced; at most
+        // MAXFLY slots / 60 pieces in flight; prefetch thin)
+        const bool busy = lds_ld(c.fx + EF_CONS + r * 4) != target;
+        const bool thin = k > (int)lds_ld(c.fx + EF_CUR);
+        while (pub < mine && (busy || mine - pub >= ENG_MAXFLY || inflight + np > 60 || (thin && inflight > ENG_THIN_PIECES))) publish_oldest();
+        if (busy) {
             const uint64_t t0 = (ENG_STAMPS && st.dbg != nullptr) ? __builtin_amdgcn_s_memrealtime() : 0;
             eng_wait_lds_ge(st, c, EF_CONS + r * 4, target, 0x10000000u | (uint32_t)seq);
             if (ENG_STAMPS && st.dbg != nullptr) stalled += __builtin_amdgcn_s_memrealtime() - t0;  // diagnostic: ring full
         }
-        while (mine - pub >= ENG_MAXFLY || inflight + np > 60) publish_oldest();
-        if (k > (int)lds_ld(c.fx + EF_CUR))
-            while (inflight > ENG_THIN_PIECES && pub < mine) publish_oldest();
         return target;
     };
     auto commit = [&](uint32_t target, int np, int nunits) {

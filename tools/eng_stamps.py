@@ -43,7 +43,10 @@ d = acc / steps
 t0 = d[0, 0]
 names = []
 for i in range(cfg.n_layer):
-    names += ["qkv", "fc0", "attn1", "fc1", "attn2", "fc2", "proj", "down"] if cfg.parallel_residual else ["qkv", "attn", "proj", "fc", "down"]
+    from lit_parrot_amd.engine import StreamEngine
+    nch = len(StreamEngine._down_chunks(cfg))
+    downs = ["down"] if nch == 1 else [f"down{j}" for j in range(nch)]
+    names += (["qkv", "fc0", "attn1", "fc1", "attn2", "fc2", "proj"] if cfg.parallel_residual else ["qkv", "attn", "proj", "fc"]) + downs
 names.append("lm_head")
 agg = {}
 for k, n in enumerate(names):
