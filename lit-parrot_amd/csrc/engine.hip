@@ -1,26 +1,29 @@
 // Stream engine: ONE launch per decode token (include/parrot_hip.h, "stream engine").
 //
 // Reference path: one iteration of generate() (generate/base.py:131-153) = GPT.forward on one token
-// (lit_gpt/model.py:63-111): embedding, per Block (:158-180) RMSNorm -> fused QKV Linear -> RoPE + KV append + attention
-// (:194-275) -> out-projection + residual -> RMSNorm -> SwiGLU MLP (:290-301) + residual, then ln_f, lm_head, arg-max.
+// (lit_gpt/model.py:63-111): embedding, per Block (:158-180) norm -> fused QKV Linear -> RoPE + KV append + attention
+// (:194-275) -> out-projection + residual, norm -> MLP (:278-301) + residual (sequential, or both branches on the block's
+// input: parallel residual, :166-171), then ln_f, lm_head, arg-max.
 //
 // Why one launch: the multi-launch step pays a ramp, a tail and a kernel boundary (~4 us in all) 161 times per token with
 // the HBM idle in between.  Here 256 workgroups (one per CU, 16 waves) stay resident for the whole token:
-//   * wave 0 is the LOADER.  It walks the CU's share of the token's byte stream - for every Linear the CU's blocks of
-//     8 output rows in the E4 layout, for every attention op the K/V rows of the CU's key range - and moves it into a
-//     ring of 7 LDS slots (17 KiB each) by LDS-DMA (global_load_lds_dwordx4, 1 KiB per wave instruction).  It never
-//     waits for a data dependency, only for a free slot, so the weights of the ops behind an activation hand-off are
-//     already on chip when the hand-off completes;
-//   * waves 1..15 are CONSUMERS.  Per op they gather the input vector into LDS (normalised, bf16), then take the op's
-//     work units round-robin as their slots land: a QUAD = 8 rows x 1024 columns (four 1-KiB pieces + one metadata
-//     word per lane) for a Linear, a K piece + V piece for attention.  Lane l of a piece holds the 32-column slice of
-//     row l % 8 in quantisation group 8 * quad + l / 8, so a lane accumulates whole groups and the only cross-lane
-//     step is one sum over the 8 lanes of a row per quad.  The wave that finishes a block's last quad sums the quads
-//     in a fixed order, applies the epilogue and publishes the 8 outputs;
+//   * one LOADER wave (two with bf16 weights) walks the CU's share of the token's byte stream - for every Linear the CU's
+//     blocks of 8 output rows in the E4 (int4) or E16 (bf16) layout, in front of them the norm's weights, for every
+//     attention op the K/V rows of the CU's key range - and moves it into a ring of 6 or 7 LDS slots (17 KiB each) by
+//     LDS-DMA (global_load_lds_dwordx4, 1 KiB per wave instruction).  It never waits for a data dependency, only for a
+//     free slot, so the weights of the ops behind an activation hand-off are already on chip when the hand-off completes;
+//   * the other 15 (14) waves are CONSUMERS.  Per op they gather the input vector into LDS (normalised, bf16), then take
+//     the op's work units round-robin as their slots land.  int4: a QUAD = 8 rows x 1024 columns (four 1-KiB pieces + one
+//     metadata word per lane); lane l of a piece holds the 32-column slice of row l % 8 in quantisation group
+//     8 * quad + l / 8, so a lane accumulates whole groups and the only cross-lane step is one sum over the 8 lanes of a
+//     row per quad.  bf16: a unit is a whole slot, 8 rows x 1024 columns.  Attention: a K piece + a V piece.  The wave that
+//     finishes a block's last unit sums the units in a fixed order, applies the epilogue and publishes the 8 outputs;
 //   * activations pass between CUs as 8-byte GRANULES {data, tag}: a write-through (sc1) store by the producer, an
 //     L1-bypassing (sc1) load by the consumer, valid when tag == the launch's epoch.  No flags, no fences, no grid
 //     barrier: a consumer simply re-reads a granule until its tag matches.  Every buffer is written once per launch.
 // Every wait is bounded: on a time-out the error word is set and every later wait falls through, so the grid drains.
+// The kernel's text is felt (14 - 15 waves share four SIMDs and a 64-KB instruction cache serves two CUs): one weight
+// format per build, and several "obvious" generalisations were measured and undone for that reason.
 #include <hip/hip_fp16.h>
 
 #include "parrot_common.h"
@@ -56,12 +59,6 @@ namespace parrot {
 #endif
 #ifndef ENG_SPIN_MODE
 #define ENG_SPIN_MODE (-1)  // -1: by weight format (bf16: waiting waves drop their priority, +0.8 %; int4: plain spin, +0.7 %)
-#endif
-#ifndef ENG_LEADER_SPREAD
-#define ENG_LEADER_SPREAD 1
-#endif
-#ifndef ENG_AB_NOGSTAMP
-#define ENG_AB_NOGSTAMP 0
 #endif
 constexpr int ENG_WGS = PARROT_ENG_WGS;
 constexpr int ENG_KEYS_PER_SPLIT = ENG_KEYS_PER_SPLIT_V;  // keys of a head that one CU attends over before a second CU joins
@@ -178,14 +175,9 @@ __device__ __forceinline__ void eng_writelane(int& v, int value, int lane) {
 }
 
 // wait until at most n of this wave's vector-memory operations are outstanding (n is wave-uniform, 0..63)
-#ifndef ENG_VMCNT_CALL
-#define ENG_VMCNT_CALL 0
-#endif
-#if ENG_VMCNT_CALL
-__device__ __attribute__((noinline)) void wait_vmcnt(int n) {  // one copy of the 64-case switch (the loader calls it from ten places)
-#else
+// (Inlined at each of its four call sites: as a function its callee prologue waits for vmcnt(0) - the pipeline of slots in
+// flight collapsed, StableLM-3B 701 -> 510 tok/s.)
 __device__ __forceinline__ void wait_vmcnt(int n) {
-#endif
 #define ENG_VM(N) case N: asm volatile("s_waitcnt vmcnt(%0)" ::"i"(N) : "memory"); break;
 #define ENG_VM4(N) ENG_VM(N) ENG_VM(N + 1) ENG_VM(N + 2) ENG_VM(N + 3)
 #define ENG_VM16(N) ENG_VM4(N) ENG_VM4(N + 4) ENG_VM4(N + 8) ENG_VM4(N + 12)
@@ -510,7 +502,7 @@ __device__ __forceinline__ void eng_loader(const EngState& st, const EngCtx& c, 
 
 // ------------------------------------------------------------------------------------------ consumer side
 struct EngCons {
-    int cw;           // consumer wave 0..6
+    int cw;           // consumer wave 0 .. NC - 1
     uint32_t cb_gen;  // consumer barrier generation
     int seq;          // ring sequence number of the current op's first slot
     int bc;           // running block count of this CU (result buffer index)
@@ -544,9 +536,6 @@ __device__ __forceinline__ void eng_release(const EngCtx& c, int seq) {
     if (c.lane == 0) lds_add(c.fx + EF_CONS + (seq % CF::NSLOT) * 4, 1u);
 }
 __device__ __forceinline__ void eng_stamp(const EngState& st, const EngCtx& c, const EngCons& w, int k, int i) {
-#if ENG_AB_NOGSTAMP
-    if (i >= 8) return;
-#endif
     if ((ENG_STAMPS && st.dbg != nullptr) && c.cu == 0 && w.cw == 0 && c.lane == 0) st.dbg[k * 16 + i] = __builtin_amdgcn_s_memrealtime();
     // every CU's {input ready, own units done} times of every op (the 100 MHz clock is chip-wide): who is late
     if ((ENG_STAMPS && st.dbg_all != nullptr) && (i == 1 || i == 2) && w.cw == 0 && c.lane == 0)
@@ -1117,7 +1106,7 @@ __device__ __forceinline__ void eng_attn_combine(const EngState& st, const EngCt
     // the group's leader CU merges the splits into the heads: every wave fetches a share of the partial states.  The leader is
     // split g % ns of group g: with split 0 every leader sat on XCD 0 (workgroup id % 8), whose CUs then ran late into
     // every later hand-off
-    if (ky.s == (ENG_LEADER_SPREAD ? ky.g % ky.ns : 0)) {
+    if (ky.s == ky.g % ky.ns) {
         const int cnt = HQ * ky.ns * PW;  // the group's heads lie back to back
         const uint64_t* pg = op->part + (int64_t)ky.g * HQ * ky.ns * PW;
         constexpr int NLD = (2 * 8 * PW + 63) / 64, NPW = (NLD + CF::NC - 1) / CF::NC;  // HQ <= 2, nsplit <= 8
