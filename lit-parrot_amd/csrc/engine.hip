@@ -33,10 +33,10 @@ namespace parrot {
 
 // experiment builds (tools/ab_engine.sh) override these
 #ifndef ENG_THIN_PIECES_V
-#define ENG_THIN_PIECES_V 4
+#define ENG_THIN_PIECES_V (-1)  // -1: by weight format (EngCfg::THIN)
 #endif
 #ifndef ENG_MAXFLY_V
-#define ENG_MAXFLY_V 3
+#define ENG_MAXFLY_V (-1)  // -1: by weight format (EngCfg::MAXFLY)
 #endif
 #ifndef ENG_KEYS_PER_SPLIT_V
 #define ENG_KEYS_PER_SPLIT_V 32
@@ -77,6 +77,12 @@ struct EngCfg {
     static constexpr int NLOAD = WFMT == PARROT_ENG_W_E16 ? 2 : 1;
     static constexpr int SPIN = ENG_SPIN_MODE >= 0 ? ENG_SPIN_MODE : (WFMT == PARROT_ENG_W_E16 ? 1 : 0);  // consumer barrier: how waiting waves wait
     static constexpr int NC = 16 - NLOAD;       // consumer waves
+    // ring slots with LDS-DMA in flight per loader (vmcnt counts at most 63 operations), and how many pieces may be
+    // outstanding when a prefetch slot (an op still behind a hand-off) is issued.  Measured per format (tools/ab_engine.sh):
+    // int4, one loader: 3 / 4 (round 2a); bf16, two loaders: 2 / 0 (StableLM-3B 832 -> 844 tok/s: less in flight while the
+    // hand-off's stores and polls share the CU's memory pipeline)
+    static constexpr int MAXFLY = ENG_MAXFLY_V >= 0 ? ENG_MAXFLY_V : (NLOAD == 2 ? 2 : 3);
+    static constexpr int THIN = ENG_THIN_PIECES_V >= 0 ? ENG_THIN_PIECES_V : (NLOAD == 2 ? 0 : 4);
     static constexpr int NSLOT = (BIG || NLOAD == 2) ? 6 : 7;  // ring slots (even with two loaders: a slot keeps its loader)
     static constexpr int MAXG = (BIG ? 9 : 6) + (NLOAD - 1);   // input groups (128 elements) per consumer wave: K <= NC * MAXG * 128
     static constexpr int MAXQ = BIG ? 16 : 11;  // units (1024 input columns) per block: K <= 1024 * MAXQ
@@ -84,8 +90,6 @@ struct EngCfg {
 constexpr int ENG_MAXQ_BIG = EngCfg<1, 0>::MAXQ, ENG_MAXQ_STD = EngCfg<0, 0>::MAXQ, ENG_MAXG_BIG = EngCfg<1, 0>::MAXG;
 constexpr int ENG_NSLOT_BIG = EngCfg<1, 0>::NSLOT, ENG_NSLOT_STD = EngCfg<0, 0>::NSLOT;
 constexpr int ENG_GROUP_STRIDE = 272;     // LDS bytes per 128-element group of an activation buffer (256 + 16: bank spread)
-constexpr int ENG_MAXFLY = ENG_MAXFLY_V;             // ring slots with LDS-DMA in flight (vmcnt counts at most 63 operations)
-constexpr int ENG_THIN_PIECES = ENG_THIN_PIECES_V;  // prefetch slots (ops behind a hand-off) are issued with at most this many pieces outstanding
 constexpr unsigned ENG_SPINS_LDS = 2000000u;
 constexpr unsigned ENG_SPINS_GLOBAL = 60000u;
 
@@ -373,7 +377,7 @@ __device__ __forceinline__ void eng_loader(const EngState& st, const EngCtx& c, 
         // MAXFLY slots / 60 pieces in flight; prefetch thin)
         const bool busy = lds_ld(c.fx + EF_CONS + r * 4) != target;
         const bool thin = k > (int)lds_ld(c.fx + EF_CUR);
-        while (pub < mine && (busy || mine - pub >= ENG_MAXFLY || inflight + np > 60 || (thin && inflight > ENG_THIN_PIECES))) publish_oldest();
+        while (pub < mine && (busy || mine - pub >= CF::MAXFLY || inflight + np > 60 || (thin && inflight > CF::THIN))) publish_oldest();
         if (busy) {
             const uint64_t t0 = (ENG_STAMPS && st.dbg != nullptr) ? __builtin_amdgcn_s_memrealtime() : 0;
             eng_wait_lds_ge(st, c, EF_CONS + r * 4, target, 0x10000000u | (uint32_t)seq);
