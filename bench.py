@@ -102,9 +102,9 @@ PMC_KERNEL_PREFIX = {"w4_gemv": "w4_gemv_kernel<1, false", "w4_gemv_dual": "w4_g
                      "w8_gemv": "w8_gemv_kernel", "attn_fused_decode": "attn_fused_decode_kernel", "eng_token": "eng_token_kernel"}
 
 
-def pmc_traffic(kernel: str, run: str = "llama2-7b-int4"):
-    """HBM bytes per launch of ``kernel`` in the run ``run`` (a workload name, "-engine" appended when the headline runs
-    on the stream engine) from the newest committed PMC summary (profiles/<tag>_<run>_pmc_traffic.json, written by
+def pmc_traffic(kernel: str, run: str = "llama2-7b-int4-multilaunch"):
+    """HBM bytes per launch of ``kernel`` in the run ``run`` (workload name + "-engine" or "-multilaunch": the executor)
+    from the newest committed PMC summary (profiles/<tag>_<run>_pmc_traffic.json, written by
     tools/summarize_profiles.py from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this benchmark).
     Counters cannot be collected inside the timed run; returns (bytes per launch or None, source file, problem or None).
     A summary without a kernel of the expected name is STALE (the kernels changed since it was taken): that is reported as a
@@ -379,7 +379,7 @@ def main() -> None:
         bytes_per_launch = kb[dom][0] / kb[dom][1]
         avg_s = stats[dom][0] / stats[dom][1] * 1e-3
         achieved = bytes_per_launch / avg_s / 1e9
-        run = args.workload + ("-engine" if args.workload == "llama2-7b-int4" and sess.eng is not None else "")
+        run = args.workload + ("-engine" if sess.eng is not None else "-multilaunch")
         traffic, traffic_src, traffic_problem = pmc_traffic(dom, run)
         if traffic_problem:
             print(f"bench.py: roofline.traffic unavailable - {traffic_problem}", file=sys.stderr, flush=True)

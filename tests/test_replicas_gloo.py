@@ -107,8 +107,8 @@ def test_committed_pmc_summary_names_the_running_kernels():
     sys.path.insert(0, str(REPO))
     import bench
 
-    for kernel, run in (("w4_gemv", "llama2-7b-int4"), ("w4_gemv_dual", "llama2-7b-int4"), ("eng_token", "llama2-7b-int4-engine"),
-                        ("eng_token", "stablelm-3b-bf16")):
+    for kernel, run in (("w4_gemv", "llama2-7b-int4-multilaunch"), ("w4_gemv_dual", "llama2-7b-int4-multilaunch"),
+                        ("eng_token", "llama2-7b-int4-engine"), ("eng_token", "stablelm-3b-bf16-engine")):
         traffic, src, problem = bench.pmc_traffic(kernel, run)
         assert problem is None and traffic and src, (kernel, run, problem)
     assert bench.pmc_traffic("no_such_kernel")[2] is not None

@@ -10,13 +10,16 @@ echo "== bench (no profiler)"
 timeout -k 10 400 python bench.py --steps 256 > $OUT/llama2-7b-int4_bench.json 2> $OUT/llama2-7b-int4_bench.err || exit 1
 timeout -k 10 400 python bench.py --steps 256 --engine 1 --no-cpu-baseline > $OUT/llama2-7b-int4-engine_bench.json 2> $OUT/llama2-7b-int4-engine_bench.err || exit 1
 echo "headline lines done"
-for w in stablelm-3b-bf16 pythia-160m-bf16; do
+for w in stablelm-3b-bf16 pythia-160m-bf16 falcon-7b-bf16; do
   timeout -k 10 600 python bench.py --workload $w --steps 256 > $OUT/${w}_bench.json 2> $OUT/${w}_bench.err || exit 1
   timeout -k 10 600 python bench.py --workload $w --steps 256 --engine 0 --no-cpu-baseline > $OUT/${w}-multilaunch_bench.json 2> $OUT/${w}-multilaunch_bench.err || exit 1
   echo "$w done"
 done
+timeout -k 10 900 python bench.py --workload falcon-40b-int4 --steps 256 --engine 1 --no-cpu-baseline > $OUT/falcon-40b-int4-engine_bench.json 2> $OUT/falcon-40b-int4-engine_bench.err || exit 1
+timeout -k 10 900 python bench.py --workload falcon-40b-int4 --steps 256 --no-cpu-baseline > $OUT/falcon-40b-int4_bench.json 2> $OUT/falcon-40b-int4_bench.err || exit 1
+echo "falcon-40b done"
 echo "== rocprofv3 kernel stats"
-for w in llama2-7b-int4 stablelm-3b-bf16 pythia-160m-bf16; do
+for w in llama2-7b-int4 stablelm-3b-bf16 pythia-160m-bf16 falcon-7b-bf16; do
   timeout -k 10 600 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/prof_$w -o $w -- python3 bench.py --workload $w --steps 64 --no-cpu-baseline > $OUT/prof_${w}.log 2>&1 || exit 1
   echo "$w profiled"
 done
