@@ -38,8 +38,13 @@ def e4_image(lin: ColBlockQuantizedLinear, partner: Optional[ColBlockQuantizedLi
         if m.quant_weight.stride() != (1, m.out_features):
             raise ParrotHipError("ColBlockQuantizedLinear.quant_weight lost its column-major layout")
         g0, g1 = k0 // 128, -(-k1 // 128)
-        s = m.scales[:, g0:g1].to(torch.bfloat16).contiguous()
-        z = m.zeros[:, g0:g1].to(torch.bfloat16).contiguous()
+        if m.tile_cols == 128:
+            s, z = m.scales[:, g0:g1], m.zeros[:, g0:g1]
+        elif m.tile_cols >= m.in_features:  # one scale per row (the reference's "gptq.int4"): the same for every group of 128
+            s, z = m.scales[:, :1].expand(-1, g1 - g0), m.zeros[:, :1].expand(-1, g1 - g0)
+        else:
+            raise ParrotHipError(f"e4_image: int4 group size {m.tile_cols} (128, or one group per row)")
+        s, z = s.to(torch.bfloat16).contiguous(), z.to(torch.bfloat16).contiguous()
         q = m.quant_weight[:, k0 // 2:k1 // 2]  # storage rows k0/2 .. k1/2 of the (K/2, N) array: contiguous
         keep.extend((s, z, q))
         return ptr(q), ptr(s), ptr(z)
@@ -83,8 +88,8 @@ class StreamEngine:
         if not linears:
             return "no Linear layers"
         if all(isinstance(m, ColBlockQuantizedLinear) for m in linears):
-            if any(m.tile_cols != 128 or m.bias is not None for m in linears):
-                return "int4 group size other than 128, or an int4 Linear with a bias"
+            if any((m.tile_cols != 128 and m.tile_cols < m.in_features) or m.bias is not None for m in linears):
+                return "int4 group size other than 128 / per row, or an int4 Linear with a bias"
         elif not all(_is_bf16_linear(m) for m in linears):
             return "the Linears are neither all int4 GPTQ nor all plain bf16"
         norms = [model.transformer.ln_f] + [n for b in model.transformer.h for n in (b.norm_1, getattr(b, "norm_2", None)) if n is not None]
@@ -155,9 +160,12 @@ class StreamEngine:
     @staticmethod
     def faster_than_multi_launch(model, window: int, int4_min_window: int) -> bool:
         """The measured choice between the two executors: bf16 weights - the engine at every window; int4 -
-        from ``int4_min_window`` KV slots on."""
+        from ``int4_min_window`` KV slots on, or at every window for multi-query models with more heads per K/V head than the
+        multi-launch step's fused attention kernel takes."""
         if any(_is_bf16_linear(m) for m in model.modules()):
             return True
+        if model.config.q_per_kv > ops.FUSED_ATTN_MAX_Q_PER_KV:
+            return True  # the multi-launch step has no fused attention for that many heads per K/V head (Falcon-7B int4: 586 vs 249 tok/s)
         return window >= int4_min_window
 
     def __init__(self, model, tokens: torch.Tensor, pos: torch.Tensor, caches: List[tuple], S: int, greedy: bool) -> None:

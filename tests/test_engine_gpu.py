@@ -266,6 +266,24 @@ def test_engine_k_chunked_down_projection(name, quant, monkeypatch):
     assert torch.equal(tok_c, tok_d) and torch.equal(log_c, log_d)
 
 
+@pytest.mark.parametrize("name", ["tiny-llama", "tiny-falcon-7b"])
+def test_engine_on_per_channel_int4(name):
+    """The reference's plain "gptq.int4" (one scale and zero per output row, quantize/gptq.py with tile_cols = -1): the E4
+    image repeats the row's pair for every group of 128 columns."""
+    cfg = Config.from_name(name)
+    sd = {k: v.to(BF) for k, v in synthetic_state_dict(cfg, 4321, perturb=True).items()}
+    qsd = o4.quantize_state_dict(sd, -1, is_linear_key)
+    with L.quantization("gptq.int4"):
+        model = L.GPT(cfg)
+    model.load_state_dict(qsd, strict=True)
+    model = model.to(BF).to(DEV).eval()
+    assert StreamEngine.supported(model) is None
+    prompt = synthetic_prompt(cfg, 9, 3)
+    tok_a, log_a = run_session(model, prompt, 20, engine=False)
+    tok_b, log_b = run_session(model, prompt, 20, engine=True, follow=tok_a.to(DEV))
+    assert_same_step(log_a, log_b, tok_a, tok_b, 9)
+
+
 def test_engine_ring_window_and_generate(monkeypatch):
     """generate() end to end on the engine, with a window smaller than the sequence (ring slots) and sampling."""
     cfg, qsd, model = int4_model("tiny-llama")

@@ -1,8 +1,8 @@
 set -o pipefail
-timeout -k 10 500 python -m pytest tests/test_engine_gpu.py -x -q > gpurun_out/eng_tests.log 2>&1 || { tail -20 gpurun_out/eng_tests.log; exit 1; }
+timeout -k 10 600 python -m pytest tests/test_engine_gpu.py -x -q > gpurun_out/eng_tests.log 2>&1 || { tail -30 gpurun_out/eng_tests.log; exit 1; }
 tail -2 gpurun_out/eng_tests.log
-for w in falcon-7b-bf16 falcon-40b-int4 llama2-7b-int4 stablelm-3b-bf16; do
-  timeout -k 10 600 python bench.py --workload $w --engine 1 --no-cpu-baseline > gpurun_out/b1_$w.json 2> gpurun_out/b1_$w.err || exit 1
+for w in "$@"; do
+  timeout -k 10 600 python bench.py --workload $w --engine 1 --no-cpu-baseline > gpurun_out/b1_$w.json 2> gpurun_out/b1_$w.err || { tail -5 gpurun_out/b1_$w.err; exit 1; }
   python -c "
 import json,sys
 r=json.loads(open('gpurun_out/b1_$w.json').read().strip().splitlines()[-1]); print('$w', round(r['value'],1), 'tok/s', round(r['ms_per_step']*1000,1), 'us engine', r['engine'], 'frac', round(r['step_roofline']['frac'],3))"
