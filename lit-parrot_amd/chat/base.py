@@ -58,7 +58,7 @@ class ChatSession(DecodeSession):
     """DecodeSession whose greedy step also runs the device-side stop check (captured in the same graph)."""
 
     def __init__(self, model: GPT, max_seq_length: int, max_tokens: int, greedy: bool) -> None:
-        super().__init__(model, max_seq_length, max_tokens, greedy, engine=False)
+        super().__init__(model, max_seq_length, max_tokens, greedy)  # the library's choice of executor (generate/base.py)
         self.stop = _StopState(self.device)
         self.n_stop_captured = None
 
@@ -138,6 +138,8 @@ def generate(
     emitted = 0     # steps t whose yield decision has been taken
     while True:
         flag = sess.stop.flag.tolist()  # one device read per chunk
+        if sess.eng is not None:
+            sess.eng.check_error()  # (the stream engine's time-out word: same sync)
         gen = sess.tokens[T: T + done].to(dtype)
         hit_t, hit_n = flag
         upto = done if hit_t < 0 else hit_t + 1
