@@ -248,6 +248,7 @@ int parrot_argmax_advance(const void* logits, int V, int64_t* tokens, int32_t* p
 #define PARROT_ENG_WGS 256
 #define PARROT_ENG_W_E4 0
 #define PARROT_ENG_W_E16 1
+#define PARROT_ENG_W_E8 2
 
 typedef struct parrot_eng_op {
     int32_t type;          /* PARROT_ENG_* */
@@ -274,10 +275,12 @@ typedef struct parrot_eng_op {
     int32_t acc;           /* GEMV over one K-chunk of a Linear whose input does not fit LDS: 0 the whole Linear; 1 first chunk
                               (the rows' sums are kept in the CU), 2 a middle chunk (added), 3 the last chunk (added, then
                               the epilogue).  W / in / K describe the chunk; needs nq < 11 (16 in the wide build) */
-    const void* W;         /* E4 / E16 weights */
+    float threshold;       /* E8: LLM.int8's outlier threshold (quantize/bnb.py:26-33: 6.0) */
+    int32_t reserved;
+    const void* W;         /* E4 / E16 / E8 weights */
     const void* norm_w;    /* K bf16 */
     const void* norm_b;    /* K bf16 or NULL (LayerNorm) */
-    const void* bias;      /* N bf16 or NULL (E16 only) */
+    const void* bias;      /* E16: N bf16 or NULL; E8: the rows' scales SCB in block order, 8 fp32 per block (SwiGLU pair: 4 + 4) */
     const void* norm2_w;   /* NULL, or a second norm of the same input and kind (the MLP's norm_2 of a parallel-residual block:
                               model.py:166-171): its result goes to the other LDS buffer, for the next op (no_gather = 1) */
     const void* norm2_b;
@@ -322,6 +325,12 @@ int parrot_e4_repack(const void* q1, const void* s1, const void* z1, const void*
 /* the same for bf16 weights: E16 image of an (N, K) nn.Linear weight (row-major bf16; w2 = fc_2 of a SwiGLU pair or NULL) */
 int64_t parrot_e16_bytes(int N, int K, int dual);
 int parrot_e16_repack(const void* w1, const void* w2, int N, int K, void* e16, void* stream);
+/* the same for LLM.int8 weights: E8 image of an (N, K) int8 matrix CB (row-major; w2 = fc_2 of a SwiGLU pair or NULL): per 8
+ * rows ceil(K / 128) pieces of 1 KiB, lane l of piece j = columns 128 j + 16 (l / 8) .. + 15 of row l % 8 */
+int64_t parrot_e8_bytes(int N, int K, int dual);
+int parrot_e8_repack(const void* w1, const void* w2, int N, int K, void* e8, void* stream);
+/* LDS bytes of one activation buffer of the int8 build: int8 image in whole units of 2048 columns + the outlier list */
+int64_t parrot_eng_lds_bytes_e8(int K, int hs, int q_per_kv, int nsplit);
 /* LDS bytes of one activation buffer for inputs of up to K elements (attention scratch for hs / q_per_kv included when
  * hs > 0); PARROT_EUNSUPPORTED when the step does not fit the CU */
 int64_t parrot_eng_lds_bytes(int K, int hs, int q_per_kv, int nsplit);

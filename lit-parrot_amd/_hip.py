@@ -34,7 +34,7 @@ _np = C.POINTER(ParrotNorm)
 ENG_GEMV, ENG_ATTN = 0, 1
 ENG_EPI_LOGITS = 4
 ENG_WGS = 256
-ENG_W_E4, ENG_W_E16 = 0, 1
+ENG_W_E4, ENG_W_E16, ENG_W_E8 = 0, 1, 2
 
 
 class EngOp(C.Structure):  # parrot_eng_op_t
@@ -42,6 +42,7 @@ class EngOp(C.Structure):  # parrot_eng_op_t
         [(n, C.c_int32) for n in ("type", "epilogue", "K", "nblocks", "nq", "buf", "norm_kind")]
         + [("norm_eps", C.c_float)]
         + [(n, C.c_int32) for n in ("in_embedding", "res_embedding", "wfmt", "res_in", "res_out", "publish", "no_gather", "blk_part", "blk_parts", "acc")]
+        + [("threshold", C.c_float), ("reserved", C.c_int32)]
         + [(n, C.c_void_p) for n in ("W", "norm_w", "norm_b", "bias", "norm2_w", "norm2_b", "inp", "out", "part", "k_cache", "v_cache")]
     )
 
@@ -91,6 +92,9 @@ SIGNATURES = {
     "parrot_e4_repack": (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp]),
     "parrot_e16_bytes": (_i64, [_i, _i, _i]),
     "parrot_e16_repack": (_i, [_vp, _vp, _i, _i, _vp, _vp]),
+    "parrot_e8_bytes": (_i64, [_i, _i, _i]),
+    "parrot_e8_repack": (_i, [_vp, _vp, _i, _i, _vp, _vp]),
+    "parrot_eng_lds_bytes_e8": (_i64, [_i, _i, _i, _i]),
     "parrot_eng_lds_bytes": (_i64, [_i, _i, _i, _i]),
     "parrot_eng_lds_total": (_i64, [_i, _i, _i, _i]),
     "parrot_eng_step": (_i, [C.POINTER(EngState), _vp]),

@@ -74,8 +74,8 @@ struct EngCfg {
     static constexpr int WF = WFMT;             // PARROT_ENG_W_E4 / _E16: one weight format per launch
     // bf16 weights: the arithmetic per byte is a quarter of int4's, the stream is the limit - two loader waves (ring slots
     // alternate between them: twice the LDS-DMA in flight, vmcnt counts per wave) and 14 consumer waves
-    static constexpr int NLOAD = WFMT == PARROT_ENG_W_E16 ? 2 : 1;
-    static constexpr int SPIN = ENG_SPIN_MODE >= 0 ? ENG_SPIN_MODE : (WFMT == PARROT_ENG_W_E16 ? 1 : 0);  // consumer barrier: how waiting waves wait
+    static constexpr int NLOAD = WFMT != PARROT_ENG_W_E4 ? 2 : 1;  // (int8 weights, E8: like bf16 - a quarter of int4's arithmetic)
+    static constexpr int SPIN = ENG_SPIN_MODE >= 0 ? ENG_SPIN_MODE : (WFMT != PARROT_ENG_W_E4 ? 1 : 0);  // consumer barrier: how waiting waves wait
     static constexpr int NC = 16 - NLOAD;       // consumer waves
     // ring slots with LDS-DMA in flight per loader (vmcnt counts at most 63 operations), and how many pieces may be
     // outstanding when a prefetch slot (an op still behind a hand-off) is issued.  Measured per format (tools/ab_engine.sh):
@@ -89,6 +89,7 @@ struct EngCfg {
 };
 constexpr int ENG_MAXQ_BIG = EngCfg<1, 0>::MAXQ, ENG_MAXQ_STD = EngCfg<0, 0>::MAXQ, ENG_MAXG_BIG = EngCfg<1, 0>::MAXG;
 constexpr int ENG_NSLOT_BIG = EngCfg<1, 0>::NSLOT, ENG_NSLOT_STD = EngCfg<0, 0>::NSLOT;
+constexpr int ENG_MAXG_E8 = EngCfg<0, PARROT_ENG_W_E8>::MAXG;
 constexpr int ENG_GROUP_STRIDE = 272;     // LDS bytes per 128-element group of an activation buffer (256 + 16: bank spread)
 constexpr unsigned ENG_SPINS_LDS = 2000000u;
 constexpr unsigned ENG_SPINS_GLOBAL = 60000u;
@@ -116,7 +117,17 @@ constexpr int EF_GATE2 = EF_GATE + 4;                     // the same for the at
 constexpr int EF_CUR = EF_GATE2 + 4;                      // index of the op whose input the consumers have (loader: how urgent a slot is)
 constexpr int EF_RED = EF_CUR + 16;                       // [ENG_RED][MAXQ][8] float: the units' partial sums of a block's rows
 template <class CF>
-constexpr int ef_bytes() { return EF_RED + ENG_RED * CF::MAXQ * 8 * 4; }
+constexpr int ef_red2() { return EF_RED + ENG_RED * CF::MAXQ * 8 * 4; }  // E8: [ENG_RED][MAXQ][8] float, the units' outlier sums
+template <class CF>
+constexpr int ef_q8() { return ef_red2<CF>() + ENG_RED * CF::MAXQ * 8 * 4; }  // E8: activation quantiser state (EQ_*)
+template <class CF>
+constexpr int ef_bytes() { return CF::WF == PARROT_ENG_W_E8 ? ef_q8<CF>() + 256 : ef_red2<CF>(); }
+// LLM.int8 (E8) activation quantiser state, byte offsets from ef_q8(): the waves' |x| maxima and outlier counts of the
+// vector being gathered, then per LDS buffer the row scale (absmax) and the outlier count
+constexpr int EQ_MAX = 0, EQ_CNT = 64, EQ_SA = 128, EQ_NO = 136;
+constexpr int ENG_Q8_CAP = 512;  // outlier list entries per buffer ({column, fp16 value} in 4 bytes)
+constexpr float ENG_MM_DEQUANT = 6.200012e-05f;  // 1 / (127 * 127), the constant of w8.hip / bitsandbytes' mm_dequant
+__device__ __forceinline__ float eng_rhalf(float v) { return __half2float(__float2half(v)); }
 
 typedef __attribute__((address_space(3))) uint32_t lds_u32_t;
 typedef const __attribute__((address_space(4))) uint32_t* cst_cu32_t;
@@ -436,7 +447,28 @@ __device__ __forceinline__ void eng_loader(const EngState& st, const EngCtx& c, 
             int bs, nb, bstep;
             eng_block_range(op, c.cu, bs, nb, bstep);
             const int nq = op->nq;
-            if (CF::WF == PARROT_ENG_W_E16) {
+            if (CF::WF == PARROT_ENG_W_E8) {
+                // int8 (LLM.int8): a piece is 8 rows x 128 columns, a slot = one unit = up to 16 pieces (2048 columns; the last
+                // unit of a row may be shorter) + the block's 8 row scales SCB (32 bytes, fetched by every lane pair) in the
+                // metadata place of EVERY slot: the outlier part of a unit dequantises single weights
+                const int pt = (op->K + 127) >> 7;  // pieces per block
+                for (int bl = 0; bl < nb; ++bl) {
+                    const int b = bs + bl * bstep;
+                    for (int Q = 0; Q < nq; ++Q) {
+                        if (!own()) {
+                            ++seq;
+                            continue;
+                        }
+                        const int npc = min(16, pt - 16 * Q);
+                        const uint32_t target = acquire(npc + 1, k);
+                        const unsigned char* src = reinterpret_cast<const unsigned char*>(op->W) + ((int64_t)b * pt + 16 * Q) * 1024 + c.lane * 16;
+                        const unsigned dst = __builtin_amdgcn_readfirstlane(ring_lds + (unsigned)((seq % NSLOT) * ENG_SLOT_BYTES));
+                        for (int j = 0; j < npc; ++j) eng_dma<true>(src + j * 1024, dst + (unsigned)(j * 1024));
+                        eng_dma<false>(reinterpret_cast<const unsigned char*>(op->bias) + (int64_t)b * 32 + (c.lane & 1) * 16, dst + (unsigned)ENG_META_OFF);
+                        commit(target, npc + 1, 1);
+                    }
+                }
+            } else if (CF::WF == PARROT_ENG_W_E16) {
                 // bf16: a slot is one unit = 16 pieces (8 rows x 1024 columns); the first slot of a block carries the block's
                 // 8 bias values (every lane fetches the same 16 bytes) where the int4 layout has its metadata
                 for (int bl = 0; bl < nb; ++bl) {
@@ -701,6 +733,88 @@ __device__ __forceinline__ void eng_gather(const EngState& st, const EngCtx& c0,
         const bool to1 = (op->buf != 0) != second;
         unsigned char* dstb = to1 ? c.buf1 : c.buf0;
         float* dxs = reinterpret_cast<float*>(c.fx + EF_XS) + (to1 ? 128 : 0);
+        if (CF::WF == PARROT_ENG_W_E8) {
+            // ---- LLM.int8 activation quantiser (oracle/int8.py::quantize_act_rows for one row; the arithmetic of w8.hip's
+            // fused kernel): fp16 cast, entries with |a| >= threshold are outliers (kept in fp16, zero in the int8 copy,
+            // excluded from the absmax), the others q = rint(a * (127 / absmax)).  LDS image: int8 [nq * 2048] then the
+            // outlier list {column | fp16 << 16}, in a fixed order (wave, group round, lane, element).
+            unsigned char* q8 = c.fx + ef_q8<CF>();
+            const float thr = op->threshold;
+            uint32_t hv[CF::MAXG];
+            float mx = 0.f;
+            int cnt = 0;
+#pragma unroll
+            for (int i = 0; i < CF::MAXG; ++i) {
+                const int g = w.cw + CF::NC * i;
+                hv[i] = 0u;
+                if (g < ngr) {
+                    uint32_t o = xv[i];
+                    const int pr = 64 * g + c.lane;
+                    if (na.kind != 0) {
+                        const uint32_t nwp = *reinterpret_cast<const uint32_t*>(nslot + min(pr, npairs - 1) * 4);
+                        uint32_t nbp = 0u;
+                        if (has_nb) nbp = *reinterpret_cast<const uint32_t*>(bslot + min(pr, npairs - 1) * 4);
+                        o = norm_apply(o, nwp, nbp, na.kind, mean, r);
+                    }
+                    if (pr >= npairs) o = 0u;
+                    const __half h0 = __float2half(bflo(o)), h1 = __float2half(bfhi(o));
+                    hv[i] = (uint32_t)__half_as_ushort(h0) | ((uint32_t)__half_as_ushort(h1) << 16);
+                    const float a0 = fabsf(__half2float(h0)), a1 = fabsf(__half2float(h1));
+                    const bool o0 = thr > 0.f && a0 >= thr, o1 = thr > 0.f && a1 >= thr;
+                    if (!o0) mx = fmaxf(mx, a0);
+                    if (!o1) mx = fmaxf(mx, a1);
+                    cnt += __popcll(__ballot(o0)) + __popcll(__ballot(o1));
+                }
+            }
+            mx = wave_max(mx);
+            if (c.lane == 0) {
+                reinterpret_cast<float*>(q8 + EQ_MAX)[w.cw] = mx;
+                reinterpret_cast<int*>(q8 + EQ_CNT)[w.cw] = cnt;
+            }
+            if (na.kind != 0) {
+                eng_release<CF>(c, w.seq);
+                if (split) eng_release<CF>(c, w.seq + 1);
+                w.seq += split ? 2 : 1;
+            }
+            eng_cbar<CF>(st, c, w);
+            int base = 0, total = 0;
+            mx = 0.f;
+            for (int t = 0; t < CF::NC; ++t) {
+                const int ct = reinterpret_cast<const int*>(q8 + EQ_CNT)[t];
+                if (t < w.cw) base += ct;
+                total += ct;
+                mx = fmaxf(mx, reinterpret_cast<const float*>(q8 + EQ_MAX)[t]);
+            }
+            const float inv = mx > 0.f ? __fdiv_rn(127.0f, mx) : 0.f;
+            uint32_t* olist = reinterpret_cast<uint32_t*>(dstb + op->nq * 2048);
+            const uint64_t lt = (1ull << c.lane) - 1ull;
+#pragma unroll
+            for (int i = 0; i < CF::MAXG; ++i) {
+                const int g = w.cw + CF::NC * i;
+                if (g < op->nq * 16) {  // (the padding up to whole units is written as zeros)
+                    const float a0 = __half2float(__ushort_as_half((unsigned short)(hv[i] & 0xffffu)));
+                    const float a1 = __half2float(__ushort_as_half((unsigned short)(hv[i] >> 16)));
+                    const bool o0 = thr > 0.f && fabsf(a0) >= thr, o1 = thr > 0.f && fabsf(a1) >= thr;
+                    const int q0 = o0 ? 0 : (int)rintf(__fmul_rn(a0, inv)), q1 = o1 ? 0 : (int)rintf(__fmul_rn(a1, inv));
+                    *reinterpret_cast<uint16_t*>(dstb + (64 * g + c.lane) * 2) = (uint16_t)((q0 & 0xff) | ((q1 & 0xff) << 8));
+                    const uint64_t b0 = __ballot(o0), b1 = __ballot(o1);
+                    if (b0 | b1) {
+                        const int col = 2 * (64 * g + c.lane);
+                        const int p0 = base + __popcll(b0 & lt) + __popcll(b1 & lt);
+                        if (o0 && p0 < ENG_Q8_CAP) olist[p0] = (uint32_t)col | (hv[i] << 16);
+                        if (o1 && p0 + (o0 ? 1 : 0) < ENG_Q8_CAP) olist[p0 + (o0 ? 1 : 0)] = (uint32_t)(col + 1) | (hv[i] & 0xffff0000u);
+                        base += __popcll(b0) + __popcll(b1);
+                    }
+                }
+            }
+            if (w.cw == 0 && c.lane == 0) {
+                reinterpret_cast<float*>(q8 + EQ_SA)[to1 ? 1 : 0] = mx;
+                reinterpret_cast<int*>(q8 + EQ_NO)[to1 ? 1 : 0] = min(total, ENG_Q8_CAP);
+                if (total > ENG_Q8_CAP) eng_fail(st, c, 0x70000000u | (uint32_t)k);  // more outliers than the list holds
+            }
+            eng_stamp(st, c, w, k, 11);
+            return;
+        }
 #pragma unroll
         for (int i = 0; i < CF::MAXG; ++i) {
             const int g = w.cw + CF::NC * i;
@@ -750,7 +864,8 @@ __device__ __forceinline__ void eng_gemv(const EngState& st, const EngCtx& c0, E
     eng_stamp(st, c, w, k, 1);
     int bs, nb, bstep;
     eng_block_range(op, c.cu, bs, nb, bstep);
-    constexpr bool e16 = CF::WF == PARROT_ENG_W_E16;
+    constexpr bool e16 = CF::WF != PARROT_ENG_W_E4;  // one unit per slot (bf16 and int8 weights)
+    constexpr bool e8 = CF::WF == PARROT_ENG_W_E8;
     const int nq = op->nq, spb = e16 ? nq : (nq + 3) >> 2;
     const unsigned char* buf = op->buf ? c.buf1 : c.buf0;
     const float* xs = reinterpret_cast<const float*>(c.fx + EF_XS) + op->buf * 128;
@@ -759,7 +874,7 @@ __device__ __forceinline__ void eng_gemv(const EngState& st, const EngCtx& c0, E
     float* resid = reinterpret_cast<float*>(c.fx + EF_RESID);
     const int r = c.lane & 7, p = c.lane >> 3;
     const int epi = op->epilogue;
-    const bool has_bias = op->bias != nullptr;
+    const bool has_bias = !e8 && op->bias != nullptr;  // (E8: that field holds the rows' scales)
     const int total = nb * nq;
     // units are dealt round-robin over the consumer waves: wave cw takes units cw, cw + NC, ...; (bl, Q) = (local block,
     // unit of the row) are stepped without a division per unit
@@ -772,7 +887,55 @@ __device__ __forceinline__ void eng_gemv(const EngState& st, const EngCtx& c0, E
         eng_wait_full<CF>(st, c, w, seq);
         const unsigned char* slot = c.ring + (seq % NSLOT) * ENG_SLOT_BYTES;
         float v;
-        if (e16) {
+        float scb_r = 0.f;  // E8: the weight row's scale
+        if (e8) {
+            // int8 unit = the slot's pieces: lane (r, p) holds columns 2048 Q + 128 i + 16 p .. + 15 of row r in piece i.
+            // C32 is exact; the outlier columns (fp16 activations x dequantised weights, LLM.int8's mixed-precision part) that
+            // fall into this unit are summed by the row's first lane in list order
+            const int npc = min(16, ((op->K + 127) >> 7) - 16 * Q);
+            const unsigned char* wq = slot + c.lane * 16;
+            const unsigned char* xq = buf + 2048 * Q + p * 16;
+            scb_r = *reinterpret_cast<const float*>(slot + ENG_META_OFF + r * 4);
+            int acc = 0;
+#pragma unroll 4
+            for (int i = 0; i < npc; ++i) {
+                const uint4 wv = *reinterpret_cast<const uint4*>(wq + i * 1024);
+                const uint4 xv = *reinterpret_cast<const uint4*>(xq + i * 128);
+                acc = __builtin_amdgcn_sdot4((int)wv.x, (int)xv.x, acc, false);
+                acc = __builtin_amdgcn_sdot4((int)wv.y, (int)xv.y, acc, false);
+                acc = __builtin_amdgcn_sdot4((int)wv.z, (int)xv.z, acc, false);
+                acc = __builtin_amdgcn_sdot4((int)wv.w, (int)xv.w, acc, false);
+            }
+            acc += __builtin_amdgcn_update_dpp(0, acc, 0x128, 0xF, 0xF, true);  // row_ror:8, then the two lane swaps: 8 lanes of a row
+            {
+                const auto sw = __builtin_amdgcn_permlane16_swap((unsigned)acc, (unsigned)acc, false, false);
+                acc = (int)sw[0] + (int)sw[1];
+            }
+            {
+                const auto sw = __builtin_amdgcn_permlane32_swap((unsigned)acc, (unsigned)acc, false, false);
+                acc = (int)sw[0] + (int)sw[1];
+            }
+            const int no = *reinterpret_cast<const int*>(c.fx + ef_q8<CF>() + EQ_NO + op->buf * 4);
+            float osum = 0.f;
+            if (no > 0) {
+                // the 8 lanes of a row share the list (entries p, p + 8, ...), then one sum over them: a fixed order
+                const uint32_t* olist = reinterpret_cast<const uint32_t*>(buf + nq * 2048);
+                for (int i = p; i < no; i += 8) {
+                    const uint32_t e = olist[i];
+                    const int col = (int)(e & 0xffffu) - 2048 * Q;
+                    if (col >= 0 && col < 2048) {
+                        const int wb = *reinterpret_cast<const signed char*>(slot + (col >> 7) * 1024 + ((((col & 127) >> 4) << 3) + r) * 16 + (col & 15));
+                        osum += __half2float(__ushort_as_half((unsigned short)(e >> 16))) * eng_rhalf(__fdiv_rn(__fmul_rn((float)wb, scb_r), 127.0f));
+                    }
+                }
+                osum = row8_allsum(osum);
+            }
+            if (c.lane < 8) {
+                reinterpret_cast<int*>(red)[(rb * MAXQ + Q) * 8 + c.lane] = acc;
+                reinterpret_cast<float*>(c.fx + ef_red2<CF>())[(rb * MAXQ + Q) * 8 + c.lane] = osum;
+            }
+            v = 0.f;
+        } else if (e16) {
             // bf16 unit = the slot's 16 pieces: lane (r, p) holds columns 1024 Q + 64 i + 8 p .. + 7 of row r in piece i
             const unsigned char* wq = slot + c.lane * 16;
             const unsigned char* xq = buf + (8 * Q) * ENG_GROUP_STRIDE + p * 16;
@@ -819,8 +982,10 @@ __device__ __forceinline__ void eng_gemv(const EngState& st, const EngCtx& c0, E
             const float acc = p0 + p1;
             v = bflo(mt) * (acc - (128.0f + bfhi(mt)) * xs[G]);
         }
-        v = row8_allsum(v);
-        if (c.lane < 8) red[(rb * MAXQ + Q) * 8 + c.lane] = v;
+        if (!e8) {
+            v = row8_allsum(v);
+            if (c.lane < 8) red[(rb * MAXQ + Q) * 8 + c.lane] = v;
+        }
         lds_drain();  // this wave's reads of the slot have returned, its partial sums are written
         uint32_t t = 0;
         if (c.lane == 0) {
@@ -833,7 +998,20 @@ __device__ __forceinline__ void eng_gemv(const EngState& st, const EngCtx& c0, E
             asm volatile("" ::: "memory");  // the partial sums are read behind the counter, not speculated above it
             lds_st(c.fx + EF_DONE + rb * 4, 0u);
             float a = 0.f;
-            for (int q = 0; q < nq; ++q) a += red[(rb * MAXQ + q) * 8 + r];
+            if (e8) {
+                // mm_dequant's separately rounded products (w8.hip), then the outlier part, both rounded to fp16
+                int c32 = 0;
+                float osum = 0.f;
+                for (int q = 0; q < nq; ++q) {
+                    c32 += reinterpret_cast<const int*>(red)[(rb * MAXQ + q) * 8 + r];
+                    osum += reinterpret_cast<const float*>(c.fx + ef_red2<CF>())[(rb * MAXQ + q) * 8 + r];
+                }
+                const float sa = *reinterpret_cast<const float*>(c.fx + ef_q8<CF>() + EQ_SA + op->buf * 4);
+                a = eng_rhalf(__fmul_rn(__fmul_rn(__fmul_rn((float)c32, ENG_MM_DEQUANT), sa), scb_r));
+                if (*reinterpret_cast<const int*>(c.fx + ef_q8<CF>() + EQ_NO + op->buf * 4) > 0) a = eng_rhalf(a + eng_rhalf(osum));
+            } else {
+                for (int q = 0; q < nq; ++q) a += red[(rb * MAXQ + q) * 8 + r];
+            }
             if (op->acc != 0) {
                 // this op is one K-chunk of a Linear whose input does not fit LDS (Falcon-40B's down-projection, K = 32768):
                 // the chunks' sums meet in a per-row accumulator - the result slot of unit MAXQ - 1, which a chunk (nq <
@@ -1377,6 +1555,28 @@ e16_repack_kernel(const bf16_t* __restrict__ w1, const bf16_t* __restrict__ w2, 
     e16[tid] = v;
 }
 
+// ------------------------------------------------------------------------------------------ E8 repack
+// int8 weights (LLM.int8's CB, row-major): per 8 rows (a block; SwiGLU pair: 4 + 4) ceil(K / 128) pieces of 1 KiB; in piece j
+// lane l holds the 16 columns 128 j + 16 (l / 8) .. + 15 of row l % 8 (zero past K).  One thread per 16-byte unit.
+__global__ void __launch_bounds__(256)
+e8_repack_kernel(const int8_t* __restrict__ w1, const int8_t* __restrict__ w2, int N, int K, int nblocks, int pt, uint4* __restrict__ e8) {
+    const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (tid >= (int64_t)nblocks * pt * 64) return;
+    const int ln = (int)(tid & 63);
+    const int64_t bj = tid >> 6;
+    const int B = (int)(bj / pt), j = (int)(bj % pt);
+    const int r = ln & 7, p = ln >> 3;
+    const bool dual = w2 != nullptr;
+    const int8_t* w = (dual && r >= 4) ? w2 : w1;
+    const int row = dual ? B * 4 + (r & 3) : B * 8 + r;
+    const int k0 = 128 * j + 16 * p;
+    uint32_t dw[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (int e = 0; e < 16; ++e)
+        if (k0 + e < K) dw[e >> 2] |= (uint32_t)(uint8_t)w[(int64_t)row * K + k0 + e] << (8 * (e & 3));
+    e8[tid] = make_uint4(dw[0], dw[1], dw[2], dw[3]);
+}
+
 static int e4_shape(int N, int K, int dual, int* nblocks, int* nq) {
     PARROT_REQUIRE(N > 0 && K > 0, "e4: N and K must be positive (N=%d K=%d)", N, K);
     PARROT_UNSUPPORTED(K % 32 == 0, "e4: K=%d must be a multiple of 32", K);
@@ -1440,6 +1640,38 @@ int parrot_e16_repack(const void* w1, const void* w2, int N, int K, void* e16, v
                   (const bf16_t*)w2, N, K, nblocks, nq, (uint4*)e16);
 }
 
+int64_t parrot_e8_bytes(int N, int K, int dual) {
+    PARROT_REQUIRE(N > 0 && K > 0, "e8: N and K must be positive (N=%d K=%d)", N, K);
+    PARROT_UNSUPPORTED(N % (dual ? 4 : 8) == 0, "e8: N=%d must be a multiple of %d", N, dual ? 4 : 8);
+    PARROT_UNSUPPORTED((K + 2047) / 2048 <= ENG_MAXQ_STD, "e8: K=%d is beyond the %d columns the stream engine is built for", K, ENG_MAXQ_STD * 2048);
+    return (int64_t)(dual ? N / 4 : N / 8) * ((K + 127) / 128) * 1024;
+}
+
+int parrot_e8_repack(const void* w1, const void* w2, int N, int K, void* e8, void* stream) {
+    PARROT_REQUIRE(w1 && e8, "e8_repack: null pointer");
+    PARROT_REQUIRE(aligned16(e8), "e8_repack: the E8 buffer must be 16-byte aligned");
+    const int64_t bytes = parrot_e8_bytes(N, K, w2 != nullptr);
+    if (bytes < 0) return (int)bytes;
+    const int nblocks = w2 != nullptr ? N / 4 : N / 8, pt = (K + 127) / 128;
+    const int64_t blocks = ((int64_t)nblocks * pt * 64 + 255) / 256;
+    PARROT_UNSUPPORTED(blocks < (1ll << 31), "e8_repack: matrix too large");
+    return launch(K_E4_REPACK, e8_repack_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const int8_t*)w1,
+                  (const int8_t*)w2, N, K, nblocks, pt, (uint4*)e8);
+}
+
+// E8: the activation image is int8 (whole units of 2048 columns) + the outlier list
+int64_t parrot_eng_lds_bytes_e8(int K, int hs, int q_per_kv, int nsplit) {
+    PARROT_REQUIRE(K > 0, "eng_lds_bytes_e8: K must be positive");
+    const int nq = (K + 2047) / 2048;
+    PARROT_UNSUPPORTED(nq <= ENG_MAXQ_STD && nq * 16 <= 14 * ENG_MAXG_E8, "stream engine: K=%d is beyond what the int8 build takes", K);
+    int64_t b = (int64_t)nq * 2048 + ENG_Q8_CAP * 4;
+    if (hs > 0) {
+        const int64_t a = eng_attn_scratch_bytes(hs, q_per_kv, nsplit);
+        if (a > b) b = a;
+    }
+    return (b + 15) / 16 * 16;
+}
+
 int64_t parrot_eng_lds_bytes(int K, int hs, int q_per_kv, int nsplit) {
     PARROT_REQUIRE(K > 0, "eng_lds_bytes: K must be positive");
     const int nq = (K + 1023) / 1024;
@@ -1455,11 +1687,12 @@ int64_t parrot_eng_lds_bytes(int K, int hs, int q_per_kv, int nsplit) {
 // which build runs (wide = 6 ring slots, inputs up to 16384) and its dynamic LDS: the narrow one when the inputs allow it and
 // it fits the CU
 static int64_t eng_pick_build(int kmax, int wfmt, int buf0_bytes, int buf1_bytes, bool* big) {
-    const bool e16 = wfmt == PARROT_ENG_W_E16;
+    const bool e16 = wfmt != PARROT_ENG_W_E4;  // two loaders: 6 ring slots
+    const bool e8 = wfmt == PARROT_ENG_W_E8;
     int64_t lds = 0;
-    for (int b = eng_is_big(kmax) ? 1 : 0; b < 2; ++b) {
+    for (int b = (!e8 && eng_is_big(kmax)) ? 1 : 0; b < (e8 ? 1 : 2); ++b) {  // (int8: units of 2048 columns, the narrow build takes K <= 22528)
         const int nslot = e16 ? (b ? EngCfg<1, PARROT_ENG_W_E16>::NSLOT : EngCfg<0, PARROT_ENG_W_E16>::NSLOT) : (b ? ENG_NSLOT_BIG : ENG_NSLOT_STD);
-        lds = (int64_t)nslot * ENG_SLOT_BYTES + buf0_bytes + buf1_bytes + EF_RED + ENG_RED * (b ? ENG_MAXQ_BIG : ENG_MAXQ_STD) * 32;
+        lds = (int64_t)nslot * ENG_SLOT_BYTES + buf0_bytes + buf1_bytes + EF_RED + ENG_RED * (b ? ENG_MAXQ_BIG : ENG_MAXQ_STD) * 32 * (e8 ? 2 : 1) + (e8 ? 256 : 0);
         *big = b != 0;
         if (lds <= 160 * 1024) break;
     }
@@ -1468,7 +1701,7 @@ static int64_t eng_pick_build(int kmax, int wfmt, int buf0_bytes, int buf1_bytes
 
 int64_t parrot_eng_lds_total(int kmax, int wfmt, int buf0_bytes, int buf1_bytes) {
     PARROT_REQUIRE(kmax > 0 && buf0_bytes > 0 && buf1_bytes > 0, "eng_lds_total: sizes must be positive");
-    PARROT_REQUIRE(wfmt == PARROT_ENG_W_E4 || wfmt == PARROT_ENG_W_E16, "eng_lds_total: unknown weight format %d", wfmt);
+    PARROT_REQUIRE(wfmt == PARROT_ENG_W_E4 || wfmt == PARROT_ENG_W_E16 || wfmt == PARROT_ENG_W_E8, "eng_lds_total: unknown weight format %d", wfmt);
     bool big;
     const int64_t lds = eng_pick_build(kmax, wfmt, buf0_bytes, buf1_bytes, &big);
     PARROT_UNSUPPORTED(lds <= 160 * 1024, "stream engine: needs %lld B of LDS", (long long)lds);
@@ -1494,7 +1727,11 @@ int parrot_eng_step(const parrot_eng_state_t* state_host, void* stream) {
     PARROT_REQUIRE((st.attn_buf ? st.lds_buf1_bytes : st.lds_buf0_bytes) >= eng_attn_scratch_bytes(st.hs, hq, st.nsplit),
                    "eng_step: LDS buffer %d smaller than the attention scratch", st.attn_buf);
     PARROT_REQUIRE(st.kmax >= 1, "eng_step: kmax (the largest input of any op) must be set");
-    {
+    if (st.wfmt == PARROT_ENG_W_E8) {
+        const int64_t need = (int64_t)((st.kmax + 2047) / 2048) * 2048 + ENG_Q8_CAP * 4;
+        PARROT_UNSUPPORTED((st.kmax + 2047) / 2048 <= ENG_MAXQ_STD, "stream engine: K=%d is beyond what the int8 build takes", st.kmax);
+        PARROT_REQUIRE(st.lds_buf0_bytes >= need || st.lds_buf1_bytes >= need, "eng_step: no LDS buffer holds an int8 input of kmax=%d elements", st.kmax);
+    } else {
         const int nqm = (st.kmax + 1023) / 1024;
         PARROT_UNSUPPORTED(nqm <= ENG_MAXQ_BIG, "stream engine: K=%d is beyond what it is built for", st.kmax);
         PARROT_REQUIRE(st.lds_buf0_bytes >= (int64_t)nqm * 8 * ENG_GROUP_STRIDE || st.lds_buf1_bytes >= (int64_t)nqm * 8 * ENG_GROUP_STRIDE,
@@ -1505,8 +1742,8 @@ int parrot_eng_step(const parrot_eng_state_t* state_host, void* stream) {
     const size_t lds = (size_t)lds_total;
     bool big;
     (void)eng_pick_build(st.kmax, st.wfmt, st.lds_buf0_bytes, st.lds_buf1_bytes, &big);
-    PARROT_REQUIRE(st.wfmt == PARROT_ENG_W_E4 || st.wfmt == PARROT_ENG_W_E16, "eng_step: unknown weight format %d", st.wfmt);
-    const bool e16 = st.wfmt == PARROT_ENG_W_E16;
+    PARROT_REQUIRE(st.wfmt == PARROT_ENG_W_E4 || st.wfmt == PARROT_ENG_W_E16 || st.wfmt == PARROT_ENG_W_E8, "eng_step: unknown weight format %d", st.wfmt);
+    const bool e16 = st.wfmt == PARROT_ENG_W_E16, e8 = st.wfmt == PARROT_ENG_W_E8;
     hipStream_t s = (hipStream_t)stream;
 #define PARROT_ENG_GO(HSV, HQV, BIGV, WFV)                                                                               \
     do {                                                                                                                 \
@@ -1521,6 +1758,7 @@ int parrot_eng_step(const parrot_eng_state_t* state_host, void* stream) {
     } while (0)
 #define PARROT_ENG_GO2(HSV, HQV)                                      \
     do {                                                              \
+        if (e8) PARROT_ENG_GO(HSV, HQV, 0, PARROT_ENG_W_E8);          \
         if (e16 && big) PARROT_ENG_GO(HSV, HQV, 1, PARROT_ENG_W_E16); \
         if (e16) PARROT_ENG_GO(HSV, HQV, 0, PARROT_ENG_W_E16);        \
         if (big) PARROT_ENG_GO(HSV, HQV, 1, PARROT_ENG_W_E4);         \

@@ -12,8 +12,9 @@ from typing import List, Optional
 import torch
 
 from . import _hip, ops
-from ._hip import (ENG_ATTN, ENG_EPI_LOGITS, ENG_GEMV, ENG_W_E4, ENG_W_E16, ENG_WGS, EPI_GELU, EPI_NONE, EPI_RESIDUAL,
-                   EPI_SWIGLU, EngOp, EngState, ParrotHipError, check, ptr)
+from ._hip import (ENG_ATTN, ENG_EPI_LOGITS, ENG_GEMV, ENG_W_E4, ENG_W_E8, ENG_W_E16, ENG_WGS, EPI_GELU, EPI_NONE,
+                   EPI_RESIDUAL, EPI_SWIGLU, EngOp, EngState, ParrotHipError, check, ptr)
+from .quantize.bnb import InferenceLinear8bitLt
 from .quantize.gptq import ColBlockQuantizedLinear
 from .rmsnorm import RMSNorm
 
@@ -73,6 +74,40 @@ def e16_image(lin: torch.nn.Linear, partner: Optional[torch.nn.Linear] = None, k
     return out
 
 
+def e8_image(lin: InferenceLinear8bitLt, partner: Optional[InferenceLinear8bitLt] = None):
+    """(E8 copy of an LLM.int8 Linear's CB - of the SwiGLU pair -, the rows' scales SCB in block order: 8 fp32 per block)."""
+    lib = _hip.load()
+    N, K = lin.out_features, lin.in_features
+    nbytes = lib.parrot_e8_bytes(N, K, int(partner is not None))
+    if nbytes < 0:
+        raise ParrotHipError(f"parrot_e8_bytes failed ({nbytes}): {_hip.last_error()}")
+    w1 = lin.weight.data.contiguous()
+    w2 = partner.weight.data.contiguous() if partner is not None else None
+    if w1.dtype != torch.int8 or (w2 is not None and w2.dtype != torch.int8):
+        raise ParrotHipError("e8_image: the weights are not quantised yet")
+    out = torch.empty((nbytes,), dtype=torch.uint8, device=w1.device)
+    check(lib.parrot_e8_repack(ptr(w1), ptr(w2) if w2 is not None else None, N, K, ptr(out), _hip.stream()), "parrot_e8_repack")
+    if partner is None:
+        scb = lin.weight.SCB.float().contiguous()
+    else:
+        scb = torch.cat([lin.weight.SCB.float().view(-1, 4), partner.weight.SCB.float().view(-1, 4)], dim=1).contiguous()
+    return out, scb
+
+
+def _is_int8_linear(m) -> bool:
+    return isinstance(m, InferenceLinear8bitLt) and m.is_quantized
+
+
+def _wfmt_of(linears) -> Optional[int]:
+    if all(isinstance(m, ColBlockQuantizedLinear) for m in linears):
+        return ENG_W_E4
+    if all(_is_int8_linear(m) for m in linears):
+        return ENG_W_E8
+    if all(_is_bf16_linear(m) for m in linears):
+        return ENG_W_E16
+    return None
+
+
 def _is_bf16_linear(m) -> bool:
     return type(m) is torch.nn.Linear and m.weight.dtype == torch.bfloat16
 
@@ -87,11 +122,13 @@ class StreamEngine:
         linears = [m for m in model.modules() if isinstance(m, torch.nn.Linear) or hasattr(m, "hip_linear")]
         if not linears:
             return "no Linear layers"
-        if all(isinstance(m, ColBlockQuantizedLinear) for m in linears):
-            if any((m.tile_cols != 128 and m.tile_cols < m.in_features) or m.bias is not None for m in linears):
-                return "int4 group size other than 128 / per row, or an int4 Linear with a bias"
-        elif not all(_is_bf16_linear(m) for m in linears):
-            return "the Linears are neither all int4 GPTQ nor all plain bf16"
+        wfmt = _wfmt_of(linears)
+        if wfmt is None:
+            return "the Linears are neither all int4 GPTQ, nor all LLM.int8, nor all plain bf16"
+        if wfmt == ENG_W_E4 and any((m.tile_cols != 128 and m.tile_cols < m.in_features) or m.bias is not None for m in linears):
+            return "int4 group size other than 128 / per row, or an int4 Linear with a bias"
+        if wfmt == ENG_W_E8 and (any(m.bias is not None for m in linears) or len({m.threshold for m in linears}) != 1):
+            return "LLM.int8 Linears with a bias, or with different thresholds"
         norms = [model.transformer.ln_f] + [n for b in model.transformer.h for n in (b.norm_1, getattr(b, "norm_2", None)) if n is not None]
         for n in norms:
             if not isinstance(n, (RMSNorm, torch.nn.LayerNorm)):
@@ -110,9 +147,10 @@ class StreamEngine:
         dev = next(model.parameters()).device
         if dev.type != "cuda" or torch.cuda.get_device_properties(dev).multi_processor_count < ENG_WGS:
             return f"the engine keeps {ENG_WGS} workgroups resident, one per CU: the device has fewer CUs"
-        wfmt = ENG_W_E4 if isinstance(linears[0], ColBlockQuantizedLinear) else ENG_W_E16
-        b0, b1, _ = StreamEngine._lds_buffers(c)
-        kmax = max([c.n_embd] + [k1 - k0 for k0, k1 in StreamEngine._down_chunks(c)])
+        if wfmt == ENG_W_E8 and len(StreamEngine._down_chunks(c, wfmt)) > 1:
+            return "an LLM.int8 down-projection wider than one LDS image (the row's absmax is over the whole input)"
+        b0, b1, _ = StreamEngine._lds_buffers(c, wfmt)
+        kmax = max([c.n_embd] + [k1 - k0 for k0, k1 in StreamEngine._down_chunks(c, wfmt)])
         if b0 < 0 or b1 < 0 or _hip.load().parrot_eng_lds_total(kmax, wfmt, b0, b1) < 0:
             return _hip.last_error()
         if wfmt == ENG_W_E4 and StreamEngine.CHUNK % 128:
@@ -134,15 +172,16 @@ class StreamEngine:
     CHUNK = 8192         # input columns per K-chunk of a down-projection wider than that
 
     @staticmethod
-    def _down_chunks(c):
-        """[k0, k1) ranges of the MLP down-projection's input: one range, or chunks when it does not fit LDS."""
+    def _down_chunks(c, wfmt=ENG_W_E16):
+        """[k0, k1) ranges of the MLP down-projection's input: one range, or chunks when it does not fit LDS (an int8 image
+        is half the size: up to 11 units of 2048 columns)."""
         K = c.intermediate_size
-        if K <= StreamEngine.CHUNK_ABOVE:
+        if K <= (22528 if wfmt == ENG_W_E8 else StreamEngine.CHUNK_ABOVE):
             return [(0, K)]
         return [(k, min(k + StreamEngine.CHUNK, K)) for k in range(0, K, StreamEngine.CHUNK)]
 
     @staticmethod
-    def _lds_buffers(c):
+    def _lds_buffers(c, wfmt=ENG_W_E16):
         """Bytes of the two LDS activation buffers and which one the attention ops use as scratch.  Consecutive Linears
         alternate between the buffers.  Sequential residual: QKV 1, out-projection 0, MLP up 1, down-projection (chunks) 0,
         1, ...; the attention scratch shares buffer 0 (idle between the QKV Linear and the out-projection).  Parallel
@@ -151,19 +190,20 @@ class StreamEngine:
         lib = _hip.load()
         hq, _, nsplit = StreamEngine._attn_shape(c)
         k = [c.n_embd, c.n_embd]
-        for i, (k0, k1) in enumerate(StreamEngine._down_chunks(c)):
+        for i, (k0, k1) in enumerate(StreamEngine._down_chunks(c, wfmt)):
             k[i & 1] = max(k[i & 1], k1 - k0)
         ab = 1 if c.parallel_residual else 0
-        sizes = [lib.parrot_eng_lds_bytes(k[b], *((c.head_size, hq, nsplit) if b == ab else (0, 0, 0))) for b in (0, 1)]
+        fn = lib.parrot_eng_lds_bytes_e8 if wfmt == ENG_W_E8 else lib.parrot_eng_lds_bytes
+        sizes = [fn(k[b], *((c.head_size, hq, nsplit) if b == ab else (0, 0, 0))) for b in (0, 1)]
         return sizes[0], sizes[1], ab
 
     @staticmethod
     def faster_than_multi_launch(model, window: int, int4_min_window: int) -> bool:
-        """The measured choice between the two executors: bf16 weights - the engine at every window; int4 -
+        """The measured choice between the two executors: bf16 and LLM.int8 weights - the engine at every window; int4 -
         from ``int4_min_window`` KV slots on, or at every window for multi-query models with more heads per K/V head than the
         multi-launch step's fused attention kernel takes."""
-        if any(_is_bf16_linear(m) for m in model.modules()):
-            return True
+        if any(_is_bf16_linear(m) or _is_int8_linear(m) for m in model.modules()):
+            return True  # (LLM.int8: Llama-2-7B 475 vs 427 tok/s)
         if model.config.q_per_kv > ops.FUSED_ATTN_MAX_Q_PER_KV:
             return True  # the multi-launch step has no fused attention for that many heads per K/V head (Falcon-7B int4: 586 vs 249 tok/s)
         return window >= int4_min_window
@@ -178,7 +218,8 @@ class StreamEngine:
         L, d, hs, inter, V = c.n_layer, c.n_embd, c.head_size, c.intermediate_size, c.padded_vocab_size
         _, vper, nsplit = self._attn_shape(c)
         swiglu = c._mlp_class == "LLaMAMLP"
-        attn_buf = self._lds_buffers(c)[2]
+        wfmt = _wfmt_of([m for m in model.modules() if isinstance(m, torch.nn.Linear) or hasattr(m, "hip_linear")])
+        attn_buf = self._lds_buffers(c, wfmt)[2]
         self.logits = torch.zeros((1, V), dtype=torch.bfloat16, device=dev)
         # granule buffers, per layer (written once per launch each): qkv, attention partials, heads, x after the
         # attention branch (sequential residual only), MLP hidden, x after the block; zero = "never written" (the epoch
@@ -200,7 +241,7 @@ class StreamEngine:
 
         images = {}
         self.kmax = 0
-        chunks = self._down_chunks(c)
+        chunks = self._down_chunks(c, wfmt)
 
         def down(i: int, res_in: int) -> None:
             """The MLP down-projection of block i: one op, or one per K-chunk with the rows' sums accumulated in the CU."""
@@ -224,15 +265,27 @@ class StreamEngine:
             if part[1] > 1 and epilogue == EPI_RESIDUAL:
                 raise ParrotHipError("stream engine: a Linear with a residual epilogue is not split into parts")
             e4 = isinstance(lin, ColBlockQuantizedLinear)
-            op.wfmt = ENG_W_E4 if e4 else ENG_W_E16
-            if not e4 and lin.bias is not None:
+            e8 = _is_int8_linear(lin)
+            op.wfmt = ENG_W_E4 if e4 else (ENG_W_E8 if e8 else ENG_W_E16)
+            if not e4 and not e8 and lin.bias is not None:
                 if partner is not None:
                     raise ParrotHipError("stream engine: a SwiGLU pair with biases is not built")
                 op.bias = ptr(lin.bias.data)
             img = images.get((id(lin), k0, k1))
             if img is None:
-                img = images[(id(lin), k0, k1)] = e4_image(lin, partner, k0, k1) if e4 else e16_image(lin, partner, k0, k1)
-                self.images.append(img)
+                if e8:
+                    if (k0, k1) != (0, lin.in_features):
+                        raise ParrotHipError("stream engine: an LLM.int8 Linear is not split into K-chunks")
+                    img = e8_image(lin, partner)  # (image, rows' scales)
+                    self.images.append(img[1])
+                else:
+                    img = e4_image(lin, partner, k0, k1) if e4 else e16_image(lin, partner, k0, k1)
+                images[(id(lin), k0, k1)] = img
+                self.images.append(img[0] if e8 else img)
+            if e8:
+                op.nq = (K + 2047) // 2048  # int8 units are 2048 columns
+                op.bias, op.threshold = img[1].data_ptr(), float(lin.threshold)
+                img = img[0]
             op.W, op.inp, op.out = img.data_ptr(), inp, out
             if norm is not None:
                 op.norm_w, op.norm_eps = ptr(norm.weight.data), float(norm.eps)
@@ -306,7 +359,7 @@ class StreamEngine:
         st.vper = vper
         st.kmax = self.kmax
         st.wfmt = ops_list[0].wfmt
-        st.lds_buf0_bytes, st.lds_buf1_bytes, st.attn_buf = self._lds_buffers(c)
+        st.lds_buf0_bytes, st.lds_buf1_bytes, st.attn_buf = self._lds_buffers(c, wfmt)
         st.arg = self.granules.data_ptr() + 8 * L * per_layer
         self.state = st
         self.n_ops = len(ops_list)

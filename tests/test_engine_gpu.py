@@ -8,7 +8,7 @@ pytestmark = pytest.mark.gpu
 import lit_parrot_amd as L  # noqa: E402
 from lit_parrot_amd import _hip  # noqa: E402
 from lit_parrot_amd.config import Config  # noqa: E402
-from lit_parrot_amd.engine import StreamEngine, e4_image, e16_image  # noqa: E402
+from lit_parrot_amd.engine import StreamEngine, e4_image, e8_image, e16_image  # noqa: E402
 from lit_parrot_amd.generate import base as gb  # noqa: E402
 from lit_parrot_amd.quantize.gptq import ColBlockQuantizedLinear, pack_nibbles  # noqa: E402
 from lit_parrot_amd.synth import is_linear_key, synthetic_prompt, synthetic_state_dict  # noqa: E402
@@ -137,7 +137,53 @@ def test_e16_repack_is_the_layout_the_header_defines(N, K, dual):
     assert got.shape == want.shape and np.array_equal(got, want)
 
 
+@pytest.mark.parametrize("N,K,dual", [(16, 128, False), (24, 352, False), (8, 4096, False), (8, 2176, True), (12, 96, True)])
+def test_e8_repack_is_the_layout_the_header_defines(N, K, dual):
+    """E8 (LLM.int8 weights): per 8 rows (4 + 4 of a SwiGLU pair) ceil(K / 128) pieces; lane l of piece j holds the 16 columns
+    128 j + 16 (l / 8) .. + 15 of row l % 8, zero past K; the rows' scales follow in block order."""
+    from lit_parrot_amd.quantize.bnb import InferenceLinear8bitLt
+
+    g = torch.Generator().manual_seed(N + K)
+    lins = []
+    for _ in range(2 if dual else 1):
+        lin = InferenceLinear8bitLt(K, N, bias=False)
+        lin.weight.data = torch.randn((N, K), generator=g)
+        lins.append(lin.to(DEV))
+    assert all(m.is_quantized for m in lins)
+    img, scb = e8_image(lins[0], lins[1] if dual else None)
+    got = img.cpu().numpy().view(np.int8)
+    w = [m.weight.data.cpu().numpy() for m in lins]
+    nblocks, pt = (N // 4 if dual else N // 8), (K + 127) // 128
+    want = np.zeros((nblocks, pt, 64, 16), dtype=np.int8)
+    for B in range(nblocks):
+        for ln in range(64):
+            r, p = ln & 7, ln >> 3
+            src = w[1] if dual and r >= 4 else w[0]
+            row = B * 4 + (r & 3) if dual else B * 8 + r
+            for j in range(pt):
+                k0 = 128 * j + 16 * p
+                n = max(0, min(16, K - k0))
+                want[B, j, ln, :n] = src[row, k0:k0 + n]
+    assert np.array_equal(got, want.reshape(-1))
+    s = [m.weight.SCB.cpu().numpy() for m in lins]
+    want_s = np.concatenate([s[0].reshape(-1, 4), s[1].reshape(-1, 4)], axis=1) if dual else s[0].reshape(-1, 8)
+    assert np.array_equal(scb.cpu().numpy().reshape(-1), want_s.reshape(-1))
+
+
 # ------------------------------------------------------------------------------------------------ the step
+def int8_model(name, threshold=6.0):
+    cfg = Config.from_name(name)
+    sd = {k: v.to(BF) for k, v in synthetic_state_dict(cfg, 4321, perturb=True).items()}
+    with L.quantization("bnb.int8"):
+        model = L.GPT(cfg)
+    model.load_state_dict(dict(sd), strict=False)
+    model = model.to(BF).to(DEV).eval()
+    for m in model.modules():
+        if hasattr(m, "threshold"):
+            m.threshold = float(threshold)
+    return cfg, sd, model
+
+
 def bf16_model(name, **overrides):
     cfg = Config.from_name(name, **overrides)
     sd = {k: v.to(BF) for k, v in synthetic_state_dict(cfg, 4321, perturb=True).items()}
@@ -282,6 +328,37 @@ def test_engine_on_per_channel_int4(name):
     tok_a, log_a = run_session(model, prompt, 20, engine=False)
     tok_b, log_b = run_session(model, prompt, 20, engine=True, follow=tok_a.to(DEV))
     assert_same_step(log_a, log_b, tok_a, tok_b, 9)
+
+
+@pytest.mark.parametrize("name,threshold", [("tiny-llama", 6.0), ("tiny-llama", 1.5), ("tiny-llama-hs128", 2.0), ("tiny-llama-gqa", 6.0),
+                                            ("tiny-falcon-40b", 2.0), ("tiny-falcon-7b", 6.0)])
+def test_engine_step_on_llm_int8_weights(name, threshold):
+    """LLM.int8 Linears on the engine (E8 layout): the activation quantiser runs in the gather (fp16 cast, outlier split at the
+    threshold, row absmax over the waves, int8 image + outlier list in LDS), units are v_dot4_i32_i8 sums (exact) plus the
+    outlier columns in fp16.  Against the multi-launch step on the same forced tokens - a lowered threshold makes a good part
+    of every input vector outliers -, run to run, and against the oracle, at the int8 path's own bound (every Linear
+    re-quantises its input: one bf16 ulp upstream can move an activation to the next int8 step)."""
+    cfg, sd, model = int8_model(name, threshold)
+    assert StreamEngine.supported(model) is None
+    prompt = synthetic_prompt(cfg, 9, 3)
+    tok_a, log_a = run_session(model, prompt, 20, engine=False)
+    tok_b, log_b = run_session(model, prompt, 20, engine=True, follow=tok_a.to(DEV))
+    d = (log_a - log_b).abs()
+    scale = max(1.0, float(log_a.abs().max()))
+    assert float(d.max()) <= 3e-2 * scale and float(d.mean()) <= 4e-3 * scale, (float(d.max()), float(d.mean()))
+    tok_c, log_c = run_session(model, prompt, 20, engine=True)
+    tok_d, log_d = run_session(model, prompt, 20, engine=True, use_graph=False)
+    assert torch.equal(tok_c, tok_d) and torch.equal(log_c, log_d)
+    oracle = om.OracleGPT(cfg, sd, "int8", threshold=threshold)
+    with torch.no_grad():
+        oracle(tok_c[:9].view(1, -1), 40, torch.arange(9))
+        for i in range(9, 13):
+            ref = oracle(tok_c[i].view(1, 1), 40, torch.tensor([i]))[0, -1].float()
+            dd = (log_c[i - 9] - ref).abs()
+            # (tokens tok_c == tok_a as long as the executors agree; the multi-launch step's own distance to the oracle is the yardstick)
+            da = (log_a[i - 9] - ref).abs() if torch.equal(tok_a[: i + 1], tok_c[: i + 1]) else dd
+            assert float(dd.max()) <= 3e-2 * max(1.0, float(ref.abs().max())), (i, float(dd.max()))
+            assert float(dd.mean()) <= max(4e-3, 1.25 * float(da.mean())), (i, float(dd.mean()), float(da.mean()))
 
 
 def test_engine_ring_window_and_generate(monkeypatch):

@@ -1,6 +1,8 @@
 set -o pipefail
-timeout -k 10 600 python -m pytest tests/test_engine_gpu.py -x -q > gpurun_out/eng_tests.log 2>&1 || { tail -30 gpurun_out/eng_tests.log; exit 1; }
-tail -2 gpurun_out/eng_tests.log
+if [ "$SKIP_TESTS" != "1" ]; then
+timeout -k 10 900 python -m pytest tests/ -x -q -m gpu > gpurun_out/gpu_tests.log 2>&1 || { tail -30 gpurun_out/gpu_tests.log; exit 1; }
+tail -2 gpurun_out/gpu_tests.log
+fi
 for w in "$@"; do
   timeout -k 10 600 python bench.py --workload $w --engine 1 --no-cpu-baseline > gpurun_out/b1_$w.json 2> gpurun_out/b1_$w.err || { tail -5 gpurun_out/b1_$w.err; exit 1; }
   python -c "
