@@ -84,12 +84,13 @@ struct EngCfg {
     static constexpr int MAXFLY = ENG_MAXFLY_V >= 0 ? ENG_MAXFLY_V : (NLOAD == 2 ? 2 : 3);
     static constexpr int THIN = ENG_THIN_PIECES_V >= 0 ? ENG_THIN_PIECES_V : (NLOAD == 2 ? 0 : 4);
     static constexpr int NSLOT = (BIG || NLOAD == 2) ? 6 : 7;  // ring slots (even with two loaders: a slot keeps its loader)
-    static constexpr int MAXG = (BIG ? 9 : 6) + (NLOAD - 1);   // input groups (128 elements) per consumer wave: K <= NC * MAXG * 128
+    // input groups (128 elements) per consumer wave: K <= NC * MAXG * 128 (int8, wide build: 11 units of 2048 columns)
+    static constexpr int MAXG = (WFMT == PARROT_ENG_W_E8 && BIG) ? 13 : (BIG ? 9 : 6) + (NLOAD - 1);
     static constexpr int MAXQ = BIG ? 16 : 11;  // units (1024 input columns) per block: K <= 1024 * MAXQ
 };
 constexpr int ENG_MAXQ_BIG = EngCfg<1, 0>::MAXQ, ENG_MAXQ_STD = EngCfg<0, 0>::MAXQ, ENG_MAXG_BIG = EngCfg<1, 0>::MAXG;
 constexpr int ENG_NSLOT_BIG = EngCfg<1, 0>::NSLOT, ENG_NSLOT_STD = EngCfg<0, 0>::NSLOT;
-constexpr int ENG_MAXG_E8 = EngCfg<0, PARROT_ENG_W_E8>::MAXG;
+constexpr int ENG_MAXG_E8 = EngCfg<0, PARROT_ENG_W_E8>::MAXG, ENG_MAXG_E8_BIG = EngCfg<1, PARROT_ENG_W_E8>::MAXG;
 constexpr int ENG_GROUP_STRIDE = 272;     // LDS bytes per 128-element group of an activation buffer (256 + 16: bank spread)
 constexpr unsigned ENG_SPINS_LDS = 2000000u;
 constexpr unsigned ENG_SPINS_GLOBAL = 60000u;
@@ -1663,7 +1664,7 @@ int parrot_e8_repack(const void* w1, const void* w2, int N, int K, void* e8, voi
 int64_t parrot_eng_lds_bytes_e8(int K, int hs, int q_per_kv, int nsplit) {
     PARROT_REQUIRE(K > 0, "eng_lds_bytes_e8: K must be positive");
     const int nq = (K + 2047) / 2048;
-    PARROT_UNSUPPORTED(nq <= ENG_MAXQ_STD && nq * 16 <= 14 * ENG_MAXG_E8, "stream engine: K=%d is beyond what the int8 build takes", K);
+    PARROT_UNSUPPORTED(nq <= ENG_MAXQ_STD && nq * 16 <= 14 * ENG_MAXG_E8_BIG, "stream engine: K=%d is beyond what the int8 build takes", K);
     int64_t b = (int64_t)nq * 2048 + ENG_Q8_CAP * 4;
     if (hs > 0) {
         const int64_t a = eng_attn_scratch_bytes(hs, q_per_kv, nsplit);
@@ -1690,7 +1691,8 @@ static int64_t eng_pick_build(int kmax, int wfmt, int buf0_bytes, int buf1_bytes
     const bool e16 = wfmt != PARROT_ENG_W_E4;  // two loaders: 6 ring slots
     const bool e8 = wfmt == PARROT_ENG_W_E8;
     int64_t lds = 0;
-    for (int b = (!e8 && eng_is_big(kmax)) ? 1 : 0; b < (e8 ? 1 : 2); ++b) {  // (int8: units of 2048 columns, the narrow build takes K <= 22528)
+    // (int8: units of 2048 columns; the narrow build gathers up to 14 * 7 groups of 128 = 12544 columns, the wide one 22528)
+    for (int b = (e8 ? ((kmax + 2047) / 2048) * 16 > 14 * ENG_MAXG_E8 : eng_is_big(kmax)) ? 1 : 0; b < 2; ++b) {
         const int nslot = e16 ? (b ? EngCfg<1, PARROT_ENG_W_E16>::NSLOT : EngCfg<0, PARROT_ENG_W_E16>::NSLOT) : (b ? ENG_NSLOT_BIG : ENG_NSLOT_STD);
         lds = (int64_t)nslot * ENG_SLOT_BYTES + buf0_bytes + buf1_bytes + EF_RED + ENG_RED * (b ? ENG_MAXQ_BIG : ENG_MAXQ_STD) * 32 * (e8 ? 2 : 1) + (e8 ? 256 : 0);
         *big = b != 0;
@@ -1758,6 +1760,7 @@ int parrot_eng_step(const parrot_eng_state_t* state_host, void* stream) {
     } while (0)
 #define PARROT_ENG_GO2(HSV, HQV)                                      \
     do {                                                              \
+        if (e8 && big) PARROT_ENG_GO(HSV, HQV, 1, PARROT_ENG_W_E8);   \
         if (e8) PARROT_ENG_GO(HSV, HQV, 0, PARROT_ENG_W_E8);          \
         if (e16 && big) PARROT_ENG_GO(HSV, HQV, 1, PARROT_ENG_W_E16); \
         if (e16) PARROT_ENG_GO(HSV, HQV, 0, PARROT_ENG_W_E16);        \

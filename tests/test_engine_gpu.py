@@ -451,25 +451,28 @@ def test_engine_at_stablelm_3b_width():
 
 
 @torch.no_grad()
-@pytest.mark.parametrize("name,mode", [("falcon-7b", None), ("falcon-40b", "gptq.int4-g128")])
+@pytest.mark.parametrize("name,mode", [("falcon-7b", None), ("falcon-40b", "gptq.int4-g128"), ("falcon-7b", "bnb.int8")])
 def test_engine_at_falcon_widths(name, mode):
     """Falcon's launch shapes, two layers deep, against the multi-launch step on the same forced tokens: Falcon-7B bf16 (71
     query heads on one K/V head = 71 virtual groups on 3 CUs each, n_embd 4544 = 4.4 units of 1024 columns, LayerNorm weight
     and bias in a slot each, shared attention norm, the 18176-column down-projection as K-chunks of 8192 + 8192 + 1792) and
-    Falcon-40B int4 g128 (8 K/V groups of 16 query heads = 64 virtual groups of 2, n_embd 8192, four K-chunks of 8192)."""
+    Falcon-40B int4 g128 (8 K/V groups of 16 query heads = 64 virtual groups of 2, n_embd 8192, four K-chunks of 8192);
+    Falcon-7B LLM.int8 on the wide int8 build."""
     from lit_parrot_amd.config import name_to_config
     from lit_parrot_amd.synth import build_synthetic_model
 
     cfg = Config(**{**name_to_config[name], "n_layer": 2})
     model = build_synthetic_model(cfg, mode, seed=1234, device=DEV)
-    assert StreamEngine.supported(model) is None and len(StreamEngine._down_chunks(cfg)) >= 3
+    int8 = mode == "bnb.int8"  # (the wide int8 build: the 18176-column input is one image of 9 units, no K-chunks)
+    assert StreamEngine.supported(model) is None and (int8 or len(StreamEngine._down_chunks(cfg)) >= 3)
+    tol_max, tol_mean = (3e-2, 4e-3) if int8 else (2 ** -5, 2e-3)
     for T, S, n in ((40, 96, 12), (600, 700, 8)):
         prompt = synthetic_prompt(cfg, T, 7)
         tok_a, log_a = run_session(model, prompt, n, engine=False, S=S)
         tok_b, log_b = run_session(model, prompt, n, engine=True, S=S, follow=tok_a.to(DEV))
         d = (log_a - log_b).abs()
         scale = max(1.0, float(log_a.abs().max()))
-        assert float(d.max()) <= 2 ** -5 * scale and float(d.mean()) <= 2e-3 * scale, (T, float(d.max()), float(d.mean()))
+        assert float(d.max()) <= tol_max * scale and float(d.mean()) <= tol_mean * scale, (T, float(d.max()), float(d.mean()))
         tok_c, log_c = run_session(model, prompt, n, engine=True, S=S)
         tok_d, log_d = run_session(model, prompt, n, engine=True, S=S, use_graph=False)
         assert torch.equal(tok_c, tok_d) and torch.equal(log_c, log_d)
