@@ -237,7 +237,8 @@ int parrot_argmax_advance(const void* logits, int V, int64_t* tokens, int32_t* p
  * grid barrier.  Weight layouts, both per 8 output rows (a block) and 1024 input columns (a unit):
  *   E4  (GPTQ int4, group 128): four 1-KiB pieces in which lane l holds the 32-column slice of row l % 8 in quantisation
  *       group 8 * unit + l / 8, plus one metadata piece per four units;
- *   E16 (bf16): sixteen 1-KiB pieces, lane l of piece i holds columns 1024 unit + 64 i + 8 (l / 8) .. + 7 of row l % 8;
+ *   E16 (bf16): up to sixteen 1-KiB pieces, lane l of piece i holds columns 1024 unit + 64 i + 8 (l / 8) .. + 7 of row l % 8
+ *       (a row's last unit has only the pieces K needs);
  *   E8  (LLM.int8, units of 2048 columns): up to sixteen pieces, lane l of piece j holds columns 128 j + 16 (l / 8) .. + 15
  *       of row l % 8; the activation quantiser (fp16 cast, outliers at `threshold`, row absmax, int8) runs in the gather.
  * A CU owns a contiguous range of blocks of every Linear.  Supported: every Linear int4 (group 128 or one per row) without

@@ -472,6 +472,7 @@ __device__ __forceinline__ void eng_loader(const EngState& st, const EngCtx& c, 
             } else if (CF::WF == PARROT_ENG_W_E16) {
                 // bf16: a slot is one unit = 16 pieces (8 rows x 1024 columns); the first slot of a block carries the block's
                 // 8 bias values (every lane fetches the same 16 bytes) where the int4 layout has its metadata
+                const int pt = (op->K + 63) >> 6;  // pieces per block (the last unit of a row may be short)
                 for (int bl = 0; bl < nb; ++bl) {
                     const int b = bs + bl * bstep;
                     for (int Q = 0; Q < nq; ++Q) {
@@ -480,11 +481,16 @@ __device__ __forceinline__ void eng_loader(const EngState& st, const EngCtx& c, 
                             continue;
                         }
                         const bool wb = Q == 0 && op->bias != nullptr;
-                        const int np = wb ? 17 : 16;
+                        const int npc = min(16, pt - 16 * Q);
+                        const int np = npc + (wb ? 1 : 0);
                         const uint32_t target = acquire(np, k);
-                        const unsigned char* src = reinterpret_cast<const unsigned char*>(op->W) + ((int64_t)b * nq + Q) * 16384 + c.lane * 16;
+                        const unsigned char* src = reinterpret_cast<const unsigned char*>(op->W) + ((int64_t)b * pt + 16 * Q) * 1024 + c.lane * 16;
                         const unsigned dst = __builtin_amdgcn_readfirstlane(ring_lds + (unsigned)((seq % NSLOT) * ENG_SLOT_BYTES));
-                        for (int j = 0; j < 16; ++j) eng_dma<true>(src + j * 1024, dst + (unsigned)(j * 1024));
+                        if (npc == 16) {
+                            for (int j = 0; j < 16; ++j) eng_dma<true>(src + j * 1024, dst + (unsigned)(j * 1024));
+                        } else {
+                            for (int j = 0; j < npc; ++j) eng_dma<true>(src + j * 1024, dst + (unsigned)(j * 1024));
+                        }
                         if (wb) eng_dma<false>(reinterpret_cast<const unsigned char*>(op->bias) + (int64_t)b * 16, dst + (unsigned)ENG_META_OFF);
                         commit(target, np, 1);
                     }
@@ -941,8 +947,9 @@ __device__ __forceinline__ void eng_gemv(const EngState& st, const EngCtx& c0, E
             const unsigned char* wq = slot + c.lane * 16;
             const unsigned char* xq = buf + (8 * Q) * ENG_GROUP_STRIDE + p * 16;
             float p0 = 0.f, p1 = 0.f;
+            const int npc = min(16, ((op->K + 63) >> 6) - 16 * Q);  // pieces of this unit (a row's last unit may be short)
 #pragma unroll 1
-            for (int i4 = 0; i4 < 16; i4 += 4) {  // four pieces (32 registers of operands) per round
+            for (int i4 = 0; i4 + 4 <= npc; i4 += 4) {  // four pieces (32 registers of operands) per round
 #pragma unroll
                 for (int ii = 0; ii < 4; ++ii) {
                     const int i = i4 + ii;
@@ -953,6 +960,15 @@ __device__ __forceinline__ void eng_gemv(const EngState& st, const EngCtx& c0, E
                     p0 = dot2_bf16(wv.z, xv.z, p0);
                     p1 = dot2_bf16(wv.w, xv.w, p1);
                 }
+            }
+#pragma unroll 1
+            for (int i = npc & ~3; i < npc; ++i) {  // (the pieces a short unit does not have were never loaded: not read)
+                const uint4 wv = *reinterpret_cast<const uint4*>(wq + i * 1024);
+                const uint4 xv = *reinterpret_cast<const uint4*>(xq + (i >> 1) * ENG_GROUP_STRIDE + (i & 1) * 128);
+                p0 = dot2_bf16(wv.x, xv.x, p0);
+                p1 = dot2_bf16(wv.y, xv.y, p1);
+                p0 = dot2_bf16(wv.z, xv.z, p0);
+                p1 = dot2_bf16(wv.w, xv.w, p1);
             }
             v = p0 + p1;
             if (Q == 0 && has_bias && c.lane < 8) redb[rb * 8 + c.lane] = bf2f(*reinterpret_cast<const bf16_t*>(slot + ENG_META_OFF + c.lane * 2));
@@ -1537,20 +1553,21 @@ e4_repack_kernel(const uint8_t* __restrict__ q1, const bf16_t* __restrict__ s1, 
 }
 
 // ------------------------------------------------------------------------------------------ E16 repack
-// bf16 weights: per 8 rows (a block) and 1024 columns (a unit = one ring slot) 16 pieces of 1 KiB; in piece i lane l holds
-// the 8 columns 1024 Q + 64 i + 8 (l / 8) .. + 7 of row l % 8.  One thread per 16-byte unit of the image.
+// bf16 weights: per 8 rows (a block) ceil(K / 64) pieces of 1 KiB; in piece j lane l holds the 8 columns 64 j + 8 (l / 8) .. + 7
+// of row l % 8 (zero past K).  A unit = one ring slot = 16 pieces (1024 columns); a row's last unit may be shorter - the
+// padding up to a whole unit is neither stored nor streamed.  One thread per 16-byte unit of the image.
 __global__ void __launch_bounds__(256)
-e16_repack_kernel(const bf16_t* __restrict__ w1, const bf16_t* __restrict__ w2, int N, int K, int nblocks, int nq, uint4* __restrict__ e16) {
+e16_repack_kernel(const bf16_t* __restrict__ w1, const bf16_t* __restrict__ w2, int N, int K, int nblocks, int pt, uint4* __restrict__ e16) {
     const int64_t tid = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (tid >= (int64_t)nblocks * nq * 1024) return;
-    const int ln = (int)(tid & 63), i = (int)((tid >> 6) & 15);
-    const int64_t bq = tid >> 10;
-    const int B = (int)(bq / nq), Q = (int)(bq % nq);
+    if (tid >= (int64_t)nblocks * pt * 64) return;
+    const int ln = (int)(tid & 63);
+    const int64_t bj = tid >> 6;
+    const int B = (int)(bj / pt), j = (int)(bj % pt);
     const int r = ln & 7, p = ln >> 3;
     const bool dual = w2 != nullptr;
     const bf16_t* w = (dual && r >= 4) ? w2 : w1;
     const int row = dual ? B * 4 + (r & 3) : B * 8 + r;
-    const int k0 = 1024 * Q + 64 * i + 8 * p;
+    const int k0 = 64 * j + 8 * p;
     uint4 v = make_uint4(0, 0, 0, 0);
     if (k0 < K) v = *reinterpret_cast<const uint4*>(w + (int64_t)row * K + k0);
     e16[tid] = v;
@@ -1626,7 +1643,7 @@ int64_t parrot_e16_bytes(int N, int K, int dual) {
     int nblocks, nq;
     const int rc = e4_shape(N, K, dual, &nblocks, &nq);  // the same block / unit grid as E4
     if (rc != PARROT_OK) return rc;
-    return (int64_t)nblocks * nq * 16384;
+    return (int64_t)nblocks * ((K + 63) / 64) * 1024;
 }
 
 int parrot_e16_repack(const void* w1, const void* w2, int N, int K, void* e16, void* stream) {
@@ -1635,10 +1652,11 @@ int parrot_e16_repack(const void* w1, const void* w2, int N, int K, void* e16, v
     int nblocks, nq;
     const int rc = e4_shape(N, K, w2 != nullptr, &nblocks, &nq);
     if (rc != PARROT_OK) return rc;
-    const int64_t blocks = ((int64_t)nblocks * nq * 1024 + 255) / 256;
+    const int pt = (K + 63) / 64;
+    const int64_t blocks = ((int64_t)nblocks * pt * 64 + 255) / 256;
     PARROT_UNSUPPORTED(blocks < (1ll << 31), "e16_repack: matrix too large");
     return launch(K_E4_REPACK, e16_repack_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)w1,
-                  (const bf16_t*)w2, N, K, nblocks, nq, (uint4*)e16);
+                  (const bf16_t*)w2, N, K, nblocks, pt, (uint4*)e16);
 }
 
 int64_t parrot_e8_bytes(int N, int K, int dual) {

@@ -50,7 +50,7 @@ def test_argument_validation_needs_no_gpu(hip_lib):
     assert hip_lib.parrot_e4_bytes(64, 16384, 0) == 8 * (64 + 4) * 1024  # 16 quads in 4 slots
     assert hip_lib.parrot_e4_bytes(64, 17408, 0) == -3 and "stream engine" in _hip.last_error()
     assert hip_lib.parrot_e16_bytes(4096, 4096, 0) == 512 * 4 * 16384 == 4096 * 4096 * 2  # bf16: no metadata, no padding here
-    assert hip_lib.parrot_e16_bytes(16, 384, 0) == 2 * 16384  # K is padded to whole 1024-column units
+    assert hip_lib.parrot_e16_bytes(16, 384, 0) == 2 * 6 * 1024  # pieces of 64 columns: a row's last unit is as short as K allows
     # the launch's LDS: 7 ring slots up to K = 11264, 6 beyond (StableLM's 16384-wide MLP input)
     assert hip_lib.parrot_eng_lds_total(11008, 0, 88 * 272, 32 * 272) == 7 * 17 * 1024 + 120 * 272 + 3552 + 16 * 11 * 32
     assert hip_lib.parrot_eng_lds_total(16384, 1, 128 * 272, 32 * 272) == 6 * 17 * 1024 + 160 * 272 + 3552 + 16 * 16 * 32

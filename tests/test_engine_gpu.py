@@ -104,21 +104,20 @@ def test_e4_repack_is_the_layout_the_header_defines(N, K):
 
 def e16_expected(w: np.ndarray, w2=None) -> np.ndarray:
     """The E16 image element by element, from the layout include/parrot_hip.h defines: per 8 rows (4 + 4 of a SwiGLU pair)
-    and 1024 columns 16 pieces; in piece i lane l holds columns 1024 Q + 64 i + 8 (l / 8) .. + 7 of row l % 8."""
+    ceil(K / 64) pieces; in piece j lane l holds columns 64 j + 8 (l / 8) .. + 7 of row l % 8 (zero past K)."""
     N, K = w.shape
     dual = w2 is not None
-    nblocks, nq = (N // 4 if dual else N // 8), (K + 1023) // 1024
-    out = np.zeros((nblocks, nq, 16, 64, 8), dtype=np.uint16)
+    nblocks, pt = (N // 4 if dual else N // 8), (K + 63) // 64
+    out = np.zeros((nblocks, pt, 64, 8), dtype=np.uint16)
     for B in range(nblocks):
         for ln in range(64):
             r, p = ln & 7, ln >> 3
             src = w2 if dual and r >= 4 else w
             row = B * 4 + (r & 3) if dual else B * 8 + r
-            for Q in range(nq):
-                for i in range(16):
-                    k0 = 1024 * Q + 64 * i + 8 * p
-                    if k0 < K:
-                        out[B, Q, i, ln] = src[row, k0:k0 + 8]
+            for j in range(pt):
+                k0 = 64 * j + 8 * p
+                if k0 < K:
+                    out[B, j, ln] = src[row, k0:k0 + 8]
     return out.reshape(-1).view(np.uint8)
 
 

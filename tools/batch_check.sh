@@ -1,6 +1,6 @@
 set -o pipefail
 if [ "$SKIP_TESTS" != "1" ]; then
-timeout -k 10 900 python -m pytest tests/ -x -q -m gpu > gpurun_out/gpu_tests.log 2>&1 || { tail -30 gpurun_out/gpu_tests.log; exit 1; }
+timeout -k 10 900 python -m pytest tests/${TESTS:-} -x -q -m gpu > gpurun_out/gpu_tests.log 2>&1 || { tail -30 gpurun_out/gpu_tests.log; exit 1; }
 tail -2 gpurun_out/gpu_tests.log
 fi
 for w in "$@"; do
