@@ -480,6 +480,32 @@ def test_engine_at_falcon_widths(name, mode):
 
 
 @torch.no_grad()
+@pytest.mark.parametrize("name", ["Llama-2-13b-hf", "Llama-2-70b-hf"])
+def test_engine_at_the_larger_llama2_widths(name):
+    """The rest of the Llama-2 family at its launch shapes, int4 g128, two layers deep: 13B (n_embd 5120, 40 heads on 6 CUs each,
+    a 13824-column down-projection: the wide build) and 70B (n_embd 8192, 8 K/V groups of 8 query heads = 32 virtual groups of
+    2, a 28672-column down-projection in four K-chunks) against the multi-launch step on the same forced tokens."""
+    from lit_parrot_amd.config import name_to_config
+    from lit_parrot_amd.synth import build_synthetic_model
+
+    cfg = Config(**{**name_to_config[name], "n_layer": 2})
+    model = build_synthetic_model(cfg, "gptq.int4-g128", seed=1234, device=DEV)
+    assert StreamEngine.supported(model) is None
+    for T, S, n in ((40, 96, 10), (500, 600, 6)):
+        prompt = synthetic_prompt(cfg, T, 7)
+        tok_a, log_a = run_session(model, prompt, n, engine=False, S=S)
+        tok_b, log_b = run_session(model, prompt, n, engine=True, S=S, follow=tok_a.to(DEV))
+        d = (log_a - log_b).abs()
+        scale = max(1.0, float(log_a.abs().max()))
+        assert float(d.max()) <= 2 ** -5 * scale and float(d.mean()) <= 2e-3 * scale, (T, float(d.max()), float(d.mean()))
+        tok_c, log_c = run_session(model, prompt, n, engine=True, S=S)
+        tok_d, log_d = run_session(model, prompt, n, engine=True, S=S, use_graph=False)
+        assert torch.equal(tok_c, tok_d) and torch.equal(log_c, log_d)
+    del model
+    torch.cuda.empty_cache()
+
+
+@torch.no_grad()
 def test_engine_soak_is_deterministic_and_error_free():
     """Hand-off races show up as run-to-run differences or as a tripped bounded wait: 600 free-running steps through a ring
     window (the K/V ring wraps nine times), twice, plus 300 steps at Llama-2-7B width - identical tokens and logits, error
