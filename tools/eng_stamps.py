@@ -100,3 +100,18 @@ dd = allc[k, :, 1] - allc[k, :, 1].min()
 print("fc op 3, units-done offset by workgroup (us), 16 per row:")
 for r0 in range(0, 256, 16):
     print("  " + " ".join(f"{float(x):5.2f}" for x in dd[r0:r0 + 16]))
+
+# is a CU's pace systematic?  Per op type: units time (done - ready) of every workgroup relative to the op's mean, averaged over
+# the layers, then summarised per XCD (workgroup id % 8) and as the correlation between the first and second half of the layers
+import numpy as np
+dur = (allc[:, :, 1] - allc[:, :, 0]).numpy()  # [op][cu]
+for n in sorted(set(names)):
+    idx = [k for k, m in enumerate(names) if m == n]
+    if len(idx) < 4 or not n.startswith(("qkv", "fc", "down", "lm")):
+        continue
+    rel = np.stack([dur[k] / dur[k].mean() for k in idx])  # [layer][cu]
+    a, b = rel[: len(idx) // 2].mean(0), rel[len(idx) // 2:].mean(0)
+    corr = float(np.corrcoef(a, b)[0, 1])
+    m = rel.mean(0)
+    per_xcd = [float(m[x::8].mean()) for x in range(8)]
+    print(f"  {n:6s} relative units time per XCD: " + " ".join(f"{v:5.3f}" for v in per_xcd) + f" | per-CU spread {m.min():.2f} .. {m.max():.2f}, half-vs-half correlation {corr:+.2f}")
