@@ -252,6 +252,8 @@ int parrot_argmax_advance(const void* logits, int V, int64_t* tokens, int32_t* p
 #define PARROT_ENG_W_E4 0
 #define PARROT_ENG_W_E16 1
 #define PARROT_ENG_W_E8 2
+#define PARROT_ENG_W_TWO_LOADERS 4 /* flag on the STATE's wfmt (and for parrot_eng_lds_total) with E4: two loader waves, 14 consumers,
+                                      6 ring slots - what bf16 and int8 weights always run with */
 
 typedef struct parrot_eng_op {
     int32_t type;          /* PARROT_ENG_* */
@@ -310,7 +312,7 @@ typedef struct parrot_eng_state {
     int32_t greedy;             /* 1: tokens[pos + 1] = argmax(logits), pos += 1 inside the launch */
     int32_t lds_buf0_bytes, lds_buf1_bytes; /* from parrot_eng_lds_bytes */
     int32_t kmax;               /* the largest K of any op: above 11264 the build with a 6-slot ring runs */
-    int32_t wfmt;               /* PARROT_ENG_W_*: the one weight format of every Linear of the launch */
+    int32_t wfmt;               /* PARROT_ENG_W_*: the one weight format of every Linear of the launch (| PARROT_ENG_W_TWO_LOADERS) */
     int32_t attn_buf;           /* which LDS buffer the attention ops use as scratch (must hold it) */
     int32_t vper;               /* virtual groups per K/V group: q_per_kv / vper = 1 or 2 query heads share one CU's pass over
                                    the group's keys (GQA / MQA: every virtual group streams the K/V rows for its own heads) */

@@ -35,6 +35,7 @@ ENG_GEMV, ENG_ATTN = 0, 1
 ENG_EPI_LOGITS = 4
 ENG_WGS = 256
 ENG_W_E4, ENG_W_E16, ENG_W_E8 = 0, 1, 2
+ENG_W_TWO_LOADERS = 4
 
 
 class EngOp(C.Structure):  # parrot_eng_op_t

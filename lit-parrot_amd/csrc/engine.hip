@@ -71,11 +71,15 @@ constexpr int ENG_RED = 16;               // block result buffers in flight
 // BIG = 1: inputs of up to 16384 elements (StableLM's MLP), whose LDS image leaves room for 6 slots.
 template <int BIG, int WFMT>
 struct EngCfg {
-    static constexpr int WF = WFMT;             // PARROT_ENG_W_E4 / _E16: one weight format per launch
+    static constexpr int WF = WFMT & 3;         // PARROT_ENG_W_E4 / _E16 / _E8: one weight format per launch
     // bf16 weights: the arithmetic per byte is a quarter of int4's, the stream is the limit - two loader waves (ring slots
     // alternate between them: twice the LDS-DMA in flight, vmcnt counts per wave) and 14 consumer waves
-    static constexpr int NLOAD = WFMT != PARROT_ENG_W_E4 ? 2 : 1;  // (int8 weights, E8: like bf16 - a quarter of int4's arithmetic)
-    static constexpr int SPIN = ENG_SPIN_MODE >= 0 ? ENG_SPIN_MODE : (WFMT != PARROT_ENG_W_E4 ? 1 : 0);  // consumer barrier: how waiting waves wait
+    // bf16 / int8 weights: a quarter of int4's arithmetic per byte, the stream is the limit - two loader waves.  int4: one
+    // loader and 15 consumers for the sequential-residual block (Llama-2-7B: 745 tok/s; 709 with two), two loaders (flag
+    // PARROT_ENG_W_TWO_LOADERS) for the parallel-residual block, where weights stream across the hand-offs (Falcon-40B 173
+    // -> 190, Falcon-7B gptq.int4 585 -> 615)
+    static constexpr int NLOAD = (WF != PARROT_ENG_W_E4 || (WFMT & PARROT_ENG_W_TWO_LOADERS)) ? 2 : 1;
+    static constexpr int SPIN = ENG_SPIN_MODE >= 0 ? ENG_SPIN_MODE : (WF != PARROT_ENG_W_E4 ? 1 : 0);  // consumer barrier: how waiting waves wait
     static constexpr int NC = 16 - NLOAD;       // consumer waves
     // ring slots with LDS-DMA in flight per loader (vmcnt counts at most 63 operations), and how many pieces may be
     // outstanding when a prefetch slot (an op still behind a hand-off) is issued.  Measured per format (tools/ab_engine.sh):
@@ -85,7 +89,7 @@ struct EngCfg {
     static constexpr int THIN = ENG_THIN_PIECES_V >= 0 ? ENG_THIN_PIECES_V : (NLOAD == 2 ? 0 : 4);
     static constexpr int NSLOT = (BIG || NLOAD == 2) ? 6 : 7;  // ring slots (even with two loaders: a slot keeps its loader)
     // input groups (128 elements) per consumer wave: K <= NC * MAXG * 128 (int8, wide build: 11 units of 2048 columns)
-    static constexpr int MAXG = (WFMT == PARROT_ENG_W_E8 && BIG) ? 13 : (BIG ? 9 : 6) + (NLOAD - 1);
+    static constexpr int MAXG = (WF == PARROT_ENG_W_E8 && BIG) ? 13 : (BIG ? 9 : 6) + (NLOAD - 1);
     static constexpr int MAXQ = BIG ? 16 : 11;  // units (1024 input columns) per block: K <= 1024 * MAXQ
 };
 constexpr int ENG_MAXQ_BIG = EngCfg<1, 0>::MAXQ, ENG_MAXQ_STD = EngCfg<0, 0>::MAXQ, ENG_MAXG_BIG = EngCfg<1, 0>::MAXG;
@@ -1706,8 +1710,8 @@ int64_t parrot_eng_lds_bytes(int K, int hs, int q_per_kv, int nsplit) {
 // which build runs (wide = 6 ring slots, inputs up to 16384) and its dynamic LDS: the narrow one when the inputs allow it and
 // it fits the CU
 static int64_t eng_pick_build(int kmax, int wfmt, int buf0_bytes, int buf1_bytes, bool* big) {
-    const bool e16 = wfmt != PARROT_ENG_W_E4;  // two loaders: 6 ring slots
-    const bool e8 = wfmt == PARROT_ENG_W_E8;
+    const bool e16 = (wfmt & 3) != PARROT_ENG_W_E4 || (wfmt & PARROT_ENG_W_TWO_LOADERS);  // two loaders: 6 ring slots
+    const bool e8 = (wfmt & 3) == PARROT_ENG_W_E8;
     int64_t lds = 0;
     // (int8: units of 2048 columns; the narrow build gathers up to 14 * 7 groups of 128 = 12544 columns, the wide one 22528)
     for (int b = (e8 ? ((kmax + 2047) / 2048) * 16 > 14 * ENG_MAXG_E8 : eng_is_big(kmax)) ? 1 : 0; b < 2; ++b) {
@@ -1721,7 +1725,7 @@ static int64_t eng_pick_build(int kmax, int wfmt, int buf0_bytes, int buf1_bytes
 
 int64_t parrot_eng_lds_total(int kmax, int wfmt, int buf0_bytes, int buf1_bytes) {
     PARROT_REQUIRE(kmax > 0 && buf0_bytes > 0 && buf1_bytes > 0, "eng_lds_total: sizes must be positive");
-    PARROT_REQUIRE(wfmt == PARROT_ENG_W_E4 || wfmt == PARROT_ENG_W_E16 || wfmt == PARROT_ENG_W_E8, "eng_lds_total: unknown weight format %d", wfmt);
+    PARROT_REQUIRE((wfmt & 3) <= PARROT_ENG_W_E8 && (wfmt & ~7) == 0, "eng_lds_total: unknown weight format %d", wfmt);
     bool big;
     const int64_t lds = eng_pick_build(kmax, wfmt, buf0_bytes, buf1_bytes, &big);
     PARROT_UNSUPPORTED(lds <= 160 * 1024, "stream engine: needs %lld B of LDS", (long long)lds);
@@ -1747,7 +1751,7 @@ int parrot_eng_step(const parrot_eng_state_t* state_host, void* stream) {
     PARROT_REQUIRE((st.attn_buf ? st.lds_buf1_bytes : st.lds_buf0_bytes) >= eng_attn_scratch_bytes(st.hs, hq, st.nsplit),
                    "eng_step: LDS buffer %d smaller than the attention scratch", st.attn_buf);
     PARROT_REQUIRE(st.kmax >= 1, "eng_step: kmax (the largest input of any op) must be set");
-    if (st.wfmt == PARROT_ENG_W_E8) {
+    if ((st.wfmt & 3) == PARROT_ENG_W_E8) {
         const int64_t need = (int64_t)((st.kmax + 2047) / 2048) * 2048 + ENG_Q8_CAP * 4;
         PARROT_UNSUPPORTED((st.kmax + 2047) / 2048 <= ENG_MAXQ_STD, "stream engine: K=%d is beyond what the int8 build takes", st.kmax);
         PARROT_REQUIRE(st.lds_buf0_bytes >= need || st.lds_buf1_bytes >= need, "eng_step: no LDS buffer holds an int8 input of kmax=%d elements", st.kmax);
@@ -1762,8 +1766,9 @@ int parrot_eng_step(const parrot_eng_state_t* state_host, void* stream) {
     const size_t lds = (size_t)lds_total;
     bool big;
     (void)eng_pick_build(st.kmax, st.wfmt, st.lds_buf0_bytes, st.lds_buf1_bytes, &big);
-    PARROT_REQUIRE(st.wfmt == PARROT_ENG_W_E4 || st.wfmt == PARROT_ENG_W_E16 || st.wfmt == PARROT_ENG_W_E8, "eng_step: unknown weight format %d", st.wfmt);
-    const bool e16 = st.wfmt == PARROT_ENG_W_E16, e8 = st.wfmt == PARROT_ENG_W_E8;
+    PARROT_REQUIRE((st.wfmt & 3) <= PARROT_ENG_W_E8 && (st.wfmt & ~7) == 0, "eng_step: unknown weight format %d", st.wfmt);
+    const bool e16 = (st.wfmt & 3) == PARROT_ENG_W_E16, e8 = (st.wfmt & 3) == PARROT_ENG_W_E8;
+    const bool two = (st.wfmt & 3) == PARROT_ENG_W_E4 && (st.wfmt & PARROT_ENG_W_TWO_LOADERS);
     hipStream_t s = (hipStream_t)stream;
 #define PARROT_ENG_GO(HSV, HQV, BIGV, WFV)                                                                               \
     do {                                                                                                                 \
@@ -1782,6 +1787,8 @@ int parrot_eng_step(const parrot_eng_state_t* state_host, void* stream) {
         if (e8) PARROT_ENG_GO(HSV, HQV, 0, PARROT_ENG_W_E8);          \
         if (e16 && big) PARROT_ENG_GO(HSV, HQV, 1, PARROT_ENG_W_E16); \
         if (e16) PARROT_ENG_GO(HSV, HQV, 0, PARROT_ENG_W_E16);        \
+        if (two && big) PARROT_ENG_GO(HSV, HQV, 1, PARROT_ENG_W_E4 | PARROT_ENG_W_TWO_LOADERS); \
+        if (two) PARROT_ENG_GO(HSV, HQV, 0, PARROT_ENG_W_E4 | PARROT_ENG_W_TWO_LOADERS);        \
         if (big) PARROT_ENG_GO(HSV, HQV, 1, PARROT_ENG_W_E4);         \
         PARROT_ENG_GO(HSV, HQV, 0, PARROT_ENG_W_E4);                  \
     } while (0)

@@ -12,7 +12,7 @@ from typing import List, Optional
 import torch
 
 from . import _hip, ops
-from ._hip import (ENG_ATTN, ENG_EPI_LOGITS, ENG_GEMV, ENG_W_E4, ENG_W_E8, ENG_W_E16, ENG_WGS, EPI_GELU, EPI_NONE,
+from ._hip import (ENG_ATTN, ENG_EPI_LOGITS, ENG_GEMV, ENG_W_E4, ENG_W_E8, ENG_W_E16, ENG_W_TWO_LOADERS, ENG_WGS, EPI_GELU, EPI_NONE,
                    EPI_RESIDUAL, EPI_SWIGLU, EngOp, EngState, ParrotHipError, check, ptr)
 from .quantize.bnb import InferenceLinear8bitLt
 from .quantize.gptq import ColBlockQuantizedLinear
@@ -151,13 +151,19 @@ class StreamEngine:
             return "an LLM.int8 down-projection wider than one LDS image (the row's absmax is over the whole input)"
         b0, b1, _ = StreamEngine._lds_buffers(c, wfmt)
         kmax = max([c.n_embd] + [k1 - k0 for k0, k1 in StreamEngine._down_chunks(c, wfmt)])
-        if b0 < 0 or b1 < 0 or _hip.load().parrot_eng_lds_total(kmax, wfmt, b0, b1) < 0:
+        if b0 < 0 or b1 < 0 or _hip.load().parrot_eng_lds_total(kmax, StreamEngine._state_wfmt(c, wfmt), b0, b1) < 0:
             return _hip.last_error()
         if wfmt == ENG_W_E4 and StreamEngine.CHUNK % 128:
             return "the K-chunks of an int4 down-projection must start on quantisation groups"
         if (c.n_embd // 8 + ENG_WGS - 1) // ENG_WGS > 8:
             return "more than 64 residual rows per CU"
         return None
+
+    @staticmethod
+    def _state_wfmt(c, wfmt: int) -> int:
+        """The launch's weight format word: int4 models with a parallel-residual block run the two-loader build (weights stream
+        across the hand-offs there: Falcon-40B 173 -> 190 tok/s; the sequential Llama block loses 5 % with it)."""
+        return wfmt | ENG_W_TWO_LOADERS if wfmt == ENG_W_E4 and c.parallel_residual else wfmt
 
     @staticmethod
     def _attn_shape(c):
@@ -205,7 +211,9 @@ class StreamEngine:
         if any(_is_bf16_linear(m) or _is_int8_linear(m) for m in model.modules()):
             return True  # (LLM.int8: Llama-2-7B 475 vs 427 tok/s)
         if model.config.q_per_kv > ops.FUSED_ATTN_MAX_Q_PER_KV:
-            return True  # the multi-launch step has no fused attention for that many heads per K/V head (Falcon-7B int4: 586 vs 249 tok/s)
+            return True  # the multi-launch step has no fused attention for that many heads per K/V head (Falcon-7B int4: 615 vs 249 tok/s)
+        if model.config.parallel_residual:
+            return True  # weights stream across the block's hand-offs (two-loader build): Falcon-40B int4 190 vs 178 tok/s
         return window >= int4_min_window
 
     def __init__(self, model, tokens: torch.Tensor, pos: torch.Tensor, caches: List[tuple], S: int, greedy: bool) -> None:
@@ -358,7 +366,7 @@ class StreamEngine:
         st.V, st.rsqrt_mode, st.nsplit, st.greedy = V, ops.RMSNORM_RSQRT_MODE, nsplit, int(greedy)
         st.vper = vper
         st.kmax = self.kmax
-        st.wfmt = ops_list[0].wfmt
+        st.wfmt = self._state_wfmt(c, ops_list[0].wfmt)
         st.lds_buf0_bytes, st.lds_buf1_bytes, st.attn_buf = self._lds_buffers(c, wfmt)
         st.arg = self.granules.data_ptr() + 8 * L * per_layer
         self.state = st
