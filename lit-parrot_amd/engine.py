@@ -174,6 +174,10 @@ class StreamEngine:
         vper = c.q_per_kv // hq
         return hq, vper, min(8, ENG_WGS // (c.n_query_groups * vper))
 
+    # parts of the MLP up-projection in front of, between and behind the two attention ops of a parallel-residual block.
+    # Measured (tools/ab_up_split.sh): StableLM-3B 830 / 825 / 822 / 834 / 824 tok/s and Falcon-40B int4 191.2 / 191.3 /
+    # 190.7 / 191.8 / 194.1 for (1,1,1) / (1,2,1) / (2,1,1) / (1,1,2) / (2,2,1): within 1.5 %, thirds kept
+    UP_SPLIT = (1, 1, 1)
     CHUNK_ABOVE = 16384  # the widest input an LDS activation buffer holds beside the ring
     CHUNK = 8192         # input columns per K-chunk of a down-projection wider than that
 
@@ -332,15 +336,20 @@ class StreamEngine:
                 # that owns the rows, the down-projection adds its rows and hands the block's output over.
                 # The attention op runs as two ops with thirds of the up-projection around them: while the partial states
                 # of a head travel to its leader CU, and the heads to everybody, weights keep streaming.
-                gemv(up, up_blocks, up_epi, 0, None, gran(i, "h"), partner=partner, no_gather=True, part=(0, 3))
+                a, b, cc = self.UP_SPLIT  # parts of the up-projection in front of, between and behind the attention halves
+                n_parts = a + b + cc
+                for j in range(a):
+                    gemv(up, up_blocks, up_epi, 0, None, gran(i, "h"), partner=partner, no_gather=True, part=(j, n_parts))
                 at.epilogue, at.buf, at.no_gather = 1, attn_buf, 1
                 ops_list.append(at)
-                gemv(up, up_blocks, up_epi, 0, None, gran(i, "h"), partner=partner, no_gather=True, part=(1, 3))
+                for j in range(a, a + b):
+                    gemv(up, up_blocks, up_epi, 0, None, gran(i, "h"), partner=partner, no_gather=True, part=(j, n_parts))
                 at2 = EngOp()
                 at2.type, at2.epilogue, at2.buf = ENG_ATTN, 2, attn_buf
                 at2.inp, at2.out, at2.part, at2.k_cache, at2.v_cache = at.inp, at.out, at.part, at.k_cache, at.v_cache
                 ops_list.append(at2)
-                gemv(up, up_blocks, up_epi, 0, None, gran(i, "h"), partner=partner, no_gather=True, part=(2, 3))
+                for j in range(a + b, n_parts):
+                    gemv(up, up_blocks, up_epi, 0, None, gran(i, "h"), partner=partner, no_gather=True, part=(j, n_parts))
                 gemv(block.attn.proj, d // 8, EPI_RESIDUAL, 1, gran(i, "y"), None, res_emb=first, res_in=0, res_out=1, publish=False)
                 down(i, 1)
             else:
