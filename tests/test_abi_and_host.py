@@ -193,3 +193,33 @@ def test_synthetic_weights_are_deterministic():
     assert all(torch.equal(a[k], b[k]) for k in a)
     assert abs(float(a["lm_head.weight"].std()) - 0.02) < 2e-3
     assert sum(is_linear_key(k) for k in a) == 1 + 4 * cfg.n_layer
+
+
+def test_stream_engine_host_plan(hip_lib):
+    """The engine's launch plan is host arithmetic: virtual groups of the attention op, K-chunks of a down-projection that does not
+    fit LDS, the LDS buffers of every BASELINE config and which kernel build they select (no GPU needed)."""
+    from lit_parrot_amd._hip import ENG_W_E4, ENG_W_E8, ENG_W_E16, ENG_W_TWO_LOADERS
+    from lit_parrot_amd.config import Config
+    from lit_parrot_amd.engine import StreamEngine as E
+
+    l7, slm, f40, f7, l70 = (Config.from_name(n) for n in ("Llama-2-7b-hf", "stablelm-base-alpha-3b", "falcon-40b", "falcon-7b", "Llama-2-70b-hf"))
+    # (query heads per virtual group, virtual groups per K/V group, CUs per virtual group)
+    assert E._attn_shape(l7) == (1, 1, 8) and E._attn_shape(slm) == (1, 1, 8)
+    assert E._attn_shape(f40) == (2, 8, 4)   # 8 groups x 16 heads -> 64 virtual groups of 2 heads on 4 CUs each
+    assert E._attn_shape(f7) == (1, 71, 3)   # one K/V head, 71 query heads -> 71 virtual groups on 3 CUs each
+    assert E._attn_shape(l70) == (2, 4, 8)
+    assert E._down_chunks(l7, ENG_W_E4) == [(0, 11008)] and E._down_chunks(slm) == [(0, 16384)]
+    assert E._down_chunks(f40, ENG_W_E4) == [(0, 8192), (8192, 16384), (16384, 24576), (24576, 32768)]
+    assert E._down_chunks(f7) == [(0, 8192), (8192, 16384), (16384, 18176)]
+    assert E._down_chunks(f7, ENG_W_E8) == [(0, 18176)]  # an int8 image is half the size, and the row's absmax needs the whole input
+    assert E._state_wfmt(l7, ENG_W_E4) == ENG_W_E4 and E._state_wfmt(f40, ENG_W_E4) == ENG_W_E4 | ENG_W_TWO_LOADERS
+    assert E._state_wfmt(slm, ENG_W_E16) == ENG_W_E16 and E._state_wfmt(f7, ENG_W_E8) == ENG_W_E8
+    for cfg, wfmt in ((l7, ENG_W_E4), (l7, ENG_W_E8), (slm, ENG_W_E16), (f40, ENG_W_E4), (f7, ENG_W_E16), (f7, ENG_W_E8), (l70, ENG_W_E4)):
+        b0, b1, ab = E._lds_buffers(cfg, wfmt)
+        assert b0 > 0 and b1 > 0 and ab == int(cfg.parallel_residual)
+        kmax = max([cfg.n_embd] + [k1 - k0 for k0, k1 in E._down_chunks(cfg, wfmt)])
+        total = hip_lib.parrot_eng_lds_total(kmax, E._state_wfmt(cfg, wfmt), b0, b1)
+        assert 100 * 1024 < total <= 160 * 1024, (cfg.name, wfmt, total)
+    # StableLM-3B is the tightest fit: 6 slots + a 16384-column image + the attention scratch in buffer 1
+    b0, b1, _ = E._lds_buffers(slm, ENG_W_E16)
+    assert hip_lib.parrot_eng_lds_total(16384, ENG_W_E16, b0, b1) > 159 * 1024
