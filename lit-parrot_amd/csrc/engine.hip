@@ -130,7 +130,7 @@ constexpr int ef_bytes() { return CF::WF == PARROT_ENG_W_E8 ? ef_q8<CF>() + 256 
 // LLM.int8 (E8) activation quantiser state, byte offsets from ef_q8(): the waves' |x| maxima and outlier counts of the
 // vector being gathered, then per LDS buffer the row scale (absmax) and the outlier count
 constexpr int EQ_MAX = 0, EQ_CNT = 64, EQ_SA = 128, EQ_NO = 136;
-constexpr int ENG_Q8_CAP = 512;  // outlier list entries per buffer ({column, fp16 value} in 4 bytes)
+constexpr int ENG_Q8_CAP = 1024;  // outlier list entries per buffer ({column, fp16 value} in 4 bytes)
 constexpr float ENG_MM_DEQUANT = 6.200012e-05f;  // 1 / (127 * 127), the constant of w8.hip / bitsandbytes' mm_dequant
 __device__ __forceinline__ float eng_rhalf(float v) { return __half2float(__float2half(v)); }
 

@@ -360,6 +360,15 @@ def test_engine_step_on_llm_int8_weights(name, threshold):
             assert float(dd.mean()) <= max(4e-3, 1.25 * float(da.mean())), (i, float(dd.mean()), float(da.mean()))
 
 
+def test_engine_int8_outlier_list_overflow_is_reported():
+    """More outlier columns in one input vector than the LDS list holds (1024): the launch sets its error word and the host
+    raises - never a silently truncated sum."""
+    cfg, _, model = int8_model("tiny-falcon-40b", threshold=1e-4)  # nearly all of the 2048-column MLP input is an "outlier"
+    prompt = synthetic_prompt(cfg, 9, 3)
+    with pytest.raises(_hip.ParrotHipError, match="error word"):
+        run_session(model, prompt, 6, engine=True)
+
+
 def test_engine_ring_window_and_generate(monkeypatch):
     """generate() end to end on the engine, with a window smaller than the sequence (ring slots) and sampling."""
     cfg, qsd, model = int4_model("tiny-llama")
