@@ -69,6 +69,10 @@ constexpr int ENG_META_OFF = 16 * 1024;   // the metadata piece of a slot, in LD
 constexpr int ENG_RED = 16;               // block result buffers in flight
 // Two builds of the kernel.  BIG = 0: inputs of up to 11264 elements, a ring of 7 slots (the Llama-2-7B family);
 // BIG = 1: inputs of up to 16384 elements (StableLM's MLP), whose LDS image leaves room for 6 slots.
+#ifndef ENG_NLOAD_MULTI
+#define ENG_NLOAD_MULTI 2  // loader waves of the stream-bound builds (the ring's 6 slots alternate between them).  Measured with 3:
+                           // Llama-2-7B int8 477 -> 466, StableLM-3B 832 -> 818, Falcon-40B int4 191 -> 176 tok/s; with 1 (int8): 382
+#endif
 template <int BIG, int WFMT>
 struct EngCfg {
     static constexpr int WF = WFMT & 3;         // PARROT_ENG_W_E4 / _E16 / _E8: one weight format per launch
@@ -78,7 +82,7 @@ struct EngCfg {
     // loader and 15 consumers for the sequential-residual block (Llama-2-7B: 745 tok/s; 709 with two), two loaders (flag
     // PARROT_ENG_W_TWO_LOADERS) for the parallel-residual block, where weights stream across the hand-offs (Falcon-40B 173
     // -> 190, Falcon-7B gptq.int4 585 -> 615)
-    static constexpr int NLOAD = (WF != PARROT_ENG_W_E4 || (WFMT & PARROT_ENG_W_TWO_LOADERS)) ? 2 : 1;
+    static constexpr int NLOAD = (WF != PARROT_ENG_W_E4 || (WFMT & PARROT_ENG_W_TWO_LOADERS)) ? ENG_NLOAD_MULTI : 1;
     static constexpr int SPIN = ENG_SPIN_MODE >= 0 ? ENG_SPIN_MODE : (WF != PARROT_ENG_W_E4 ? 1 : 0);  // consumer barrier: how waiting waves wait
     static constexpr int NC = 16 - NLOAD;       // consumer waves
     // ring slots with LDS-DMA in flight per loader (vmcnt counts at most 63 operations), and how many pieces may be
@@ -87,9 +91,9 @@ struct EngCfg {
     // hand-off's stores and polls share the CU's memory pipeline)
     static constexpr int MAXFLY = ENG_MAXFLY_V >= 0 ? ENG_MAXFLY_V : (NLOAD == 2 ? 2 : 3);
     static constexpr int THIN = ENG_THIN_PIECES_V >= 0 ? ENG_THIN_PIECES_V : (NLOAD == 2 ? 0 : 4);
-    static constexpr int NSLOT = (BIG || NLOAD == 2) ? 6 : 7;  // ring slots (even with two loaders: a slot keeps its loader)
+    static constexpr int NSLOT = (BIG || NLOAD >= 2) ? 6 : 7;  // ring slots (a multiple of the loader count: a slot keeps its loader)
     // input groups (128 elements) per consumer wave: K <= NC * MAXG * 128 (int8, wide build: 11 units of 2048 columns)
-    static constexpr int MAXG = (WF == PARROT_ENG_W_E8 && BIG) ? 13 : (BIG ? 9 : 6) + (NLOAD - 1);
+    static constexpr int MAXG = (WF == PARROT_ENG_W_E8 && BIG) ? 14 : (BIG ? 9 : 6) + (NLOAD - 1);
     static constexpr int MAXQ = BIG ? 16 : 11;  // units (1024 input columns) per block: K <= 1024 * MAXQ
 };
 constexpr int ENG_MAXQ_BIG = EngCfg<1, 0>::MAXQ, ENG_MAXQ_STD = EngCfg<0, 0>::MAXQ, ENG_MAXG_BIG = EngCfg<1, 0>::MAXG;
@@ -1686,7 +1690,7 @@ int parrot_e8_repack(const void* w1, const void* w2, int N, int K, void* e8, voi
 int64_t parrot_eng_lds_bytes_e8(int K, int hs, int q_per_kv, int nsplit) {
     PARROT_REQUIRE(K > 0, "eng_lds_bytes_e8: K must be positive");
     const int nq = (K + 2047) / 2048;
-    PARROT_UNSUPPORTED(nq <= ENG_MAXQ_STD && nq * 16 <= 14 * ENG_MAXG_E8_BIG, "stream engine: K=%d is beyond what the int8 build takes", K);
+    PARROT_UNSUPPORTED(nq <= ENG_MAXQ_STD && nq * 16 <= (16 - ENG_NLOAD_MULTI) * ENG_MAXG_E8_BIG, "stream engine: K=%d is beyond what the int8 build takes", K);
     int64_t b = (int64_t)nq * 2048 + ENG_Q8_CAP * 4;
     if (hs > 0) {
         const int64_t a = eng_attn_scratch_bytes(hs, q_per_kv, nsplit);
@@ -1714,7 +1718,7 @@ static int64_t eng_pick_build(int kmax, int wfmt, int buf0_bytes, int buf1_bytes
     const bool e8 = (wfmt & 3) == PARROT_ENG_W_E8;
     int64_t lds = 0;
     // (int8: units of 2048 columns; the narrow build gathers up to 14 * 7 groups of 128 = 12544 columns, the wide one 22528)
-    for (int b = (e8 ? ((kmax + 2047) / 2048) * 16 > 14 * ENG_MAXG_E8 : eng_is_big(kmax)) ? 1 : 0; b < 2; ++b) {
+    for (int b = (e8 ? ((kmax + 2047) / 2048) * 16 > (16 - ENG_NLOAD_MULTI) * ENG_MAXG_E8 : eng_is_big(kmax)) ? 1 : 0; b < 2; ++b) {
         const int nslot = e16 ? (b ? EngCfg<1, PARROT_ENG_W_E16>::NSLOT : EngCfg<0, PARROT_ENG_W_E16>::NSLOT) : (b ? ENG_NSLOT_BIG : ENG_NSLOT_STD);
         lds = (int64_t)nslot * ENG_SLOT_BYTES + buf0_bytes + buf1_bytes + EF_RED + ENG_RED * (b ? ENG_MAXQ_BIG : ENG_MAXQ_STD) * 32 * (e8 ? 2 : 1) + (e8 ? 256 : 0);
         *big = b != 0;
