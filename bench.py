@@ -83,13 +83,16 @@ def token_bytes(cfg, mode, context):
     return weights, kv + cfg.n_embd * 2
 
 
-def kernel_bytes_per_token(cfg, mode):
-    """Algorithmic bytes handled by each kernel id of the library during one token (for the roofline object)."""
+def kernel_bytes_per_token(cfg, mode, fused_attn_proj: bool = False):
+    """Algorithmic bytes handled by each kernel id of the library during one token (for the roofline object).
+    ``fused_attn_proj``: the out-projection's bytes belong to the attention + projection launch, not to a GEMV launch."""
     lb = linear_bytes(cfg, mode)
     L = cfg.n_layer
     prefix = {None: "bf16_gemv", "bnb.int8": "w8_gemv"}.get(mode, "w4c_gemv" if (mode or "").startswith(("bnb.nf4", "bnb.fp4")) else "w4_gemv")
-    single = [k for k in lb if k not in ("mlp.fc_1", "mlp.fc_2", "lm_head")]
+    single = [k for k in lb if k not in ("mlp.fc_1", "mlp.fc_2", "lm_head") and not (fused_attn_proj and k == "attn.proj")]
     res = {prefix: (sum(lb[k] for k in single) * L + lb["lm_head"], len(single) * L + 1)}
+    if fused_attn_proj:
+        res["attn_proj_w4"] = (lb["attn.proj"] * L, L)  # (+ the K/V rows of the context, a few % at the bench's windows)
     if "mlp.fc_1" in lb:
         dual = prefix if mode == "bnb.int8" else prefix + "_dual"
         b, n = res.get(dual, (0, 0))
@@ -97,7 +100,7 @@ def kernel_bytes_per_token(cfg, mode):
     return res  # {kernel name: (bytes per token, launches per token)}
 
 
-PMC_KERNEL_PREFIX = {"w4_gemv": "w4_gemv_kernel<1, false", "w4_gemv_dual": "w4_gemv_kernel<1, true",
+PMC_KERNEL_PREFIX = {"w4_gemv": "w4_gemv_kernel<1, false", "w4_gemv_dual": "w4_gemv_kernel<1, true", "attn_proj_w4": "attn_proj_w4_kernel",
                      "bf16_gemv": "bf16_gemv_kernel<1, false", "bf16_gemv_dual": "bf16_gemv_kernel<1, true",
                      "w8_gemv": "w8_gemv_kernel", "attn_fused_decode": "attn_fused_decode_kernel", "eng_token": "eng_token_kernel"}
 
@@ -127,6 +130,68 @@ def pmc_traffic(kernel: str, run: str = "llama2-7b-int4-multilaunch"):
     if tot_n:
         return tot_b / tot_n, f.name, None
     return None, f.name, f"STALE: {f.name} holds no kernel named {prefix}*"
+
+
+class Watchdog:
+    """Phase markers on stderr and a host watchdog: a run that goes silent must say WHERE.  ``phase(name)`` prints one line
+    per phase (model built / repacked / prefill / captured / warm-up / timed / profiled / cpu baseline); a daemon thread that
+    sees no phase change (or ``touch()``) for ``limit_s`` seconds prints the phase and the stream engine's host-visible
+    words (first error code, epoch of the last completed launch: pinned host memory, read without a HIP call - a stuck
+    device queue cannot block this thread) and ends the process with status 3 through ``os._exit``: an exit, never a
+    re-exec, and nothing that waits for the GPU."""
+
+    def __init__(self, limit_s: float = 300.0, tag: str = "bench.py") -> None:
+        import threading
+
+        self.limit_s, self.tag = float(limit_s), tag
+        self.t_start = self.t_last = time.monotonic()
+        self.name = "start"
+        self.words = None  # callable -> (first error code, last completed epoch), set once a stream engine exists
+        self._stop = threading.Event()
+        self._thread = threading.Thread(target=self._watch, daemon=True)
+        if self.limit_s > 0:
+            self._thread.start()
+
+    def phase(self, name: str) -> None:
+        now = time.monotonic()
+        print(f"{self.tag}: phase '{name}' at +{now - self.t_start:.1f} s (previous: '{self.name}', {now - self.t_last:.1f} s)", file=sys.stderr, flush=True)
+        self.name, self.t_last = name, now
+
+    def touch(self) -> None:
+        self.t_last = time.monotonic()
+
+    def describe(self) -> str:
+        txt = f"no progress for {time.monotonic() - self.t_last:.0f} s in phase '{self.name}'"
+        if self.words is not None:
+            try:
+                err, epoch = self.words()
+                txt += f"; stream engine host words: first error {err:#x}, last completed launch epoch {epoch}"
+            except Exception as e:  # the report must not die on its way out
+                txt += f"; stream engine host words unreadable ({e})"
+        return txt
+
+    def _watch(self) -> None:
+        while not self._stop.wait(min(1.0, self.limit_s / 4)):
+            if time.monotonic() - self.t_last > self.limit_s:
+                print(f"{self.tag}: WATCHDOG: {self.describe()} - ending the process with status 3", file=sys.stderr, flush=True)
+                os._exit(3)
+
+    def stop(self) -> None:
+        self._stop.set()
+
+
+def committed_full_cpu_run(workload: str):
+    """SURVEY 8(d) asks for >= 8 decode tokens of the workload on the host CPU; at ~33 s per token (the reference's CPU path
+    dequantises every matrix on every call) that does not fit the default run, so the line carries the committed figure of
+    the `--cpu-full` run beside the bounded sample, with its source file."""
+    for f in sorted((REPO / "profiles").glob(f"*_{workload}_cpu-full_bench.json"), reverse=True):
+        try:
+            cb = json.loads(f.read_text())["cpu_baseline"]
+            return {"value": cb["value"], "unit": cb["unit"], "cores": cb["cores"], "kind": cb["kind"], "sample": cb["sample"],
+                    "source": f"profiles/{f.name} (bench.py --cpu-full, an earlier run on the same kind of box)"}
+        except (OSError, KeyError, ValueError):
+            continue
+    return None
 
 
 def rank_env():
@@ -237,7 +302,7 @@ def cpu_pythia_leg():
     return {"value": (y.numel() - 128) / el, "unit": "tokens/s", "seconds": el, "sample": "pythia-160m fp32, 128-token prompt + 64 greedy tokens, prefill included"}
 
 
-def cpu_baseline(cfg, mode, model, prompt_cpu, budget_s: float = 20.0, min_tokens: int = 1):
+def cpu_baseline(cfg, mode, model, prompt_cpu, budget_s: float = 20.0, min_tokens: int = 1, wd=None, workload: str = ""):
     """Time the CPU oracle (port of the reference path) on the host cores: the Pythia-160M leg always, then a bounded sample
     of THIS workload - a short prompt prefix, then single-token decode steps until ~budget_s of CPU work, at least
     ``min_tokens`` of them (``--cpu-full`` asks for the 8 that SURVEY §8(d) names: ~33 s each on Llama-2-7B, because the
@@ -246,6 +311,11 @@ def cpu_baseline(cfg, mode, model, prompt_cpu, budget_s: float = 20.0, min_token
     from oracle import model as om
 
     out = {"value": None, "unit": "tokens/s", "cores": torch.get_num_threads(), "kind": "port", "pythia_160m_fp32": cpu_pythia_leg()}
+    full = committed_full_cpu_run(workload)
+    if full is not None:
+        out["full_run"] = full
+    if wd is not None:
+        wd.phase("cpu baseline: workload leg")
     tile_cols = 128 if (mode or "").endswith("g128") else -1
     sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
     if mode == "bnb.int8" or (mode or "").startswith(("bnb.nf4", "bnb.fp4")):
@@ -265,6 +335,8 @@ def cpu_baseline(cfg, mode, model, prompt_cpu, budget_s: float = 20.0, min_token
             n += 1
             el = time.perf_counter() - t0
             print(f"bench.py: cpu_baseline token {n} after {el:.0f} s", file=sys.stderr, flush=True)  # a long leg stays visibly alive
+            if wd is not None:
+                wd.touch()
             if (el > budget_s and n >= min_tokens) or n >= 60:
                 break
     out.update(value=n / el, sample=f"{n} single-token decode steps after a {T0}-token prompt ({el:.1f} s), same weights, oracle/model.py on the host CPU")
@@ -283,6 +355,8 @@ def main() -> None:
     ap.add_argument("--devices", default="", help="comma list of HIP_VISIBLE_DEVICES values for the replicas spawned by --gpus N (default 0..N-1)")
     ap.add_argument("--attn-split-keys", type=int, default=0, help="A/B: window slots per sequence split of the decode attention (default: the library's)")
     ap.add_argument("--engine", type=int, default=-1, help="1 / 0: force the one-launch stream engine on / off (default: the library's choice)")
+    ap.add_argument("--fuse-attn-proj", type=int, default=-1, help="A/B: 1 / 0 attention + out-projection of the multi-launch step in one launch / two (default: the library's)")
+    ap.add_argument("--watchdog", type=float, default=300.0, help="seconds without a phase change before the run reports where it is stuck and exits 3 (0: off)")
     args = ap.parse_args()
 
     rank, local, world = rank_env()
@@ -321,55 +395,74 @@ def main() -> None:
         from lit_parrot_amd import ops as _ops
 
         _ops.ATTN_SPLIT_KEYS = args.attn_split_keys
+    if args.fuse_attn_proj >= 0:
+        from lit_parrot_amd import ops as _ops
+
+        _ops.FUSE_ATTN_PROJ = bool(args.fuse_attn_proj)
+    wd = Watchdog(args.watchdog, tag=f"bench.py[{rank}]")
     cfg_name, mode, T, dtype_label = WORKLOADS[args.workload]
     cfg = Config.from_name(cfg_name)
     total = T + args.warmup + args.steps + 1
     assert total <= cfg.block_size, "prompt + warmup + steps must fit block_size"
     t_build = time.perf_counter()
+    wd.phase("building the synthetic model")
     model = build_synthetic_model(cfg, mode, seed=1234, device=device)
     prompt = synthetic_prompt(cfg, T, seed=1234 + rank, device="cpu")
     torch.cuda.synchronize(device)
     t_build = time.perf_counter() - t_build
 
     with torch.no_grad():
+        wd.phase("session (kernel-layout repacks of the executor, KV caches)")
         sess = _session(model, total, total, greedy=True)
+        if sess.eng is not None:
+            wd.words = sess.eng.progress
+        wd.phase("first prefill (lazy W4K repacks)")
         # one untimed prefill first: the int4 weights are repacked to the kernel layout lazily at first use (a one-time
         # load cost, 161 repack launches), workspaces are allocated, code objects are loaded
         sess.prefill(prompt.to(device))
         torch.cuda.synchronize(device)
+        wd.phase("timed prefill")
         t_pre = time.perf_counter()
         logits = sess.prefill(prompt.to(device))
         L.ops.argmax_advance(logits, sess.tokens, sess.pos)
         torch.cuda.synchronize(device)
         t_pre = time.perf_counter() - t_pre
+        wd.phase("graph capture")
         sess.capture()
+        wd.phase(f"warm-up, {args.warmup} steps")
         for _ in range(args.warmup):
             sess.step()
         barrier(world, device)
+        sess.check_error()  # an executor whose in-launch waits gave up decodes garbage FASTER than a healthy one: never time it
         if replica is not None:  # spawned replica: tell the parent, then wait to be released together with the others
             print("READY", flush=True)
             if sys.stdin.readline().strip() != "GO":
                 raise SystemExit("replica: released without GO")
+        wd.phase(f"timed region, {args.steps} steps")
         t0 = time.perf_counter()
         for _ in range(args.steps):
             sess.step()
         barrier(world, device)
         elapsed = time.perf_counter() - t0
+        sess.check_error()  # (after the clock stopped: the check syncs)
         elapsed_max, units = max_over_ranks(elapsed, args.steps, world, device)
         pos_end = int(sess.pos.item())
         assert pos_end == T + args.warmup + args.steps, (pos_end, T, args.warmup, args.steps)
 
         # per-kernel durations: the same step, launched eagerly with every dispatch bracketed by HIP events
+        wd.phase("per-kernel HIP events")
         prof_steps = 8
         _hip.prof_begin()
         for _ in range(prof_steps):
             sess._step()
         stats = _hip.prof_end()
+        sess.check_error()
+    wd.phase("summary")
 
     ms_per_step = elapsed_max / args.steps * 1e3
     ctx_mean = T + args.warmup + args.steps / 2.0
     w_bytes, kv_bytes = token_bytes(cfg, mode, ctx_mean)
-    kb = kernel_bytes_per_token(cfg, mode)
+    kb = kernel_bytes_per_token(cfg, mode, "attn_proj_w4" in stats)
     kb["eng_token"] = (w_bytes + kv_bytes, 1)  # the stream engine: the whole token is one launch
     dom = max(stats, key=lambda k: stats[k][0])
     kernels = {k: {"avg_us": v[0] / v[1] * 1e3, "launches_per_token": v[1] / prof_steps, "ms_per_token": v[0] / prof_steps}
@@ -421,19 +514,22 @@ def main() -> None:
                              "frac": prefill_flops / t_pre / 1e12 / MFMA_BF16_PEAK_TFLOPS, "linear_flops": prefill_flops},
         "build_s": t_build,
         "engine": sess.eng is not None,
+        "fused_attn_proj": bool(sess.eng is None and "attn_proj_w4" in stats),
     }
     if replica is not None:  # the parent aggregates: it needs this replica's own clock
         result.update(elapsed_s=elapsed, device=os.environ.get("HIP_VISIBLE_DEVICES", "?"), cpu_baseline=None)
         if rank == 0 and not args.no_cpu_baseline and int(os.environ.get("PARROT_BENCH_WORLD", "1")) == 1:
-            result["cpu_baseline"] = cpu_baseline(cfg, mode, model, prompt, args.cpu_budget, 8 if args.cpu_full else 1)
+            result["cpu_baseline"] = cpu_baseline(cfg, mode, model, prompt, args.cpu_budget, 8 if args.cpu_full else 1, wd, args.workload)
+        wd.stop()
         print(json.dumps(result), flush=True)
         return
     if rank == 0:
         if args.no_cpu_baseline or world > 1:
             result["cpu_baseline"] = None
         else:
-            result["cpu_baseline"] = cpu_baseline(cfg, mode, model, prompt, args.cpu_budget, 8 if args.cpu_full else 1)
+            result["cpu_baseline"] = cpu_baseline(cfg, mode, model, prompt, args.cpu_budget, 8 if args.cpu_full else 1, wd, args.workload)
         print(json.dumps(result), flush=True)
+    wd.stop()
     if world > 1:
         import torch.distributed as dist
 

@@ -201,6 +201,21 @@ int parrot_attn_fused_decode(const void* qkv, const void* rope_cos, const void* 
                              const int32_t* pos, int n_groups, int q_per_kv, int hs, int S, int nsplit,
                              void* workspace, void* tickets, void* k_cache, void* v_cache, void* y,
                              void* stream);
+/* The same decode step of CausalSelfAttention AND the int4 out-projection with its residual add behind it in ONE launch
+ * (lit_gpt/model.py:208-254 followed by :171 / :178-179 `x = x + proj(y)`; the Linear is ColBlockQuantizedLinear.forward,
+ * quantize/gptq.py:254-264): the projection's workgroups stream their W4K rows into registers while the attention runs and
+ * take the heads over inside the launch.  Whole window in one workgroup per (group, chunk of query heads): windows the caller
+ * would split (parrot_attn_fused_decode with nsplit > 1) keep the two-launch path.
+ * heads: [n_head*hs] bf16 scratch that ONLY this entry point touches (it is handed over between workgroups with write-through
+ * stores / L1-bypassing loads); packed: W4K image of the (N, n_head*hs) projection; bias: bf16 [N] or NULL; residual: bf16 [N]
+ * or NULL (may alias out); sync4: four zero-initialised uint32 (arrival counters, re-armed by the kernel; word 2 is set when
+ * the in-launch wait timed out: the caller must treat the step as failed and zero the words);
+ * max_workgroups: workgroups of 1024 threads that are resident at once on the device (its CU count): the launch never
+ * holds more, else PARROT_EUNSUPPORTED.                                                                                      */
+int parrot_attn_proj_w4(const void* qkv, const void* rope_cos, const void* rope_sin, int n_elem, const int32_t* pos,
+                        int n_groups, int q_per_kv, int hs, int S, void* k_cache, void* v_cache, void* heads,
+                        const void* packed, const void* bias, const void* residual, void* out, int N, int group,
+                        void* sync4, int max_workgroups, void* stream);
 /* ---- small ops of the step ----------------------------------------------------------
  * x[m] = wte[tokens[(pos ? *pos : 0) + m]]   (lit_gpt/model.py:99)                    */
 int parrot_embedding(const void* wte, int d, const int64_t* tokens, const int32_t* pos, int M,
@@ -303,7 +318,9 @@ typedef struct parrot_eng_state {
     int64_t* tokens;
     int32_t* pos;
     uint32_t* epoch;            /* 1 word, starts at 1; the launch tags its granules with it and leaves epoch + 1 */
-    uint32_t* err;              /* 1 word, zero-initialised; non-zero after a bounded wait gave up */
+    uint32_t* err;              /* 1 word, zero-initialised; non-zero after a bounded wait gave up: the code of the FIRST failure
+                                   (0xT0000000 | op or ring sequence number; T: 1 loader / ring slot, 2 consumer barrier, 3 slot
+                                   never landed, 4 / 5 / 6 hand-off of a Linear / attention / arg-max, 7 table check) */
     const void* wte;
     const void* rope_cos;       /* fp16 [block_size][n_elem] */
     const void* rope_sin;
@@ -319,6 +336,8 @@ typedef struct parrot_eng_state {
     uint64_t* arg;              /* 2 * 256 granules: every CU's arg-max candidate {value, index} */
     uint64_t* dbg;              /* NULL, or nops * 16 words: 100 MHz stamps of workgroup 0 (diagnostic runs only) */
     uint64_t* dbg_all;          /* NULL, or nops * 256 * 2 words: {input ready, units done} stamps of every workgroup */
+    uint32_t* host_words;       /* NULL, or 2 words of PINNED HOST memory (device-accessible): [0] the first error code, [1] the
+                                   epoch of the last launch that ran to its end - a host watchdog reads them without a HIP call */
 } parrot_eng_state_t;
 
 /* bytes of the E4 image of an (N, K) int4 matrix with group 128 (dual = 1: the SwiGLU pair, N rows each) */

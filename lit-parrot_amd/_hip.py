@@ -54,7 +54,7 @@ class EngState(C.Structure):  # parrot_eng_state_t
         + [(n, C.c_void_p) for n in ("tokens", "pos", "epoch", "err", "wte", "rope_cos", "rope_sin")]
         + [(n, C.c_int32) for n in ("n_elem", "n_groups", "q_per_kv", "hs", "S", "V", "rsqrt_mode", "nsplit", "greedy",
                                     "lds_buf0_bytes", "lds_buf1_bytes", "kmax", "wfmt", "attn_buf", "vper")]
-        + [(n, C.c_void_p) for n in ("arg", "dbg", "dbg_all")]
+        + [(n, C.c_void_p) for n in ("arg", "dbg", "dbg_all", "host_words")]
     )
 
 
@@ -87,6 +87,7 @@ SIGNATURES = {
     "parrot_attn_workspace_floats": (_i64, [_i, _i, _i, _i]),
     "parrot_attn_decode": (_i, [_vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _i, _vp]),
     "parrot_attn_fused_decode": (_i, [_vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "parrot_attn_proj_w4": (_i, [_vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _i, _vp]),
     "parrot_attn_prefill_scratch_elems": (_i64, [_i, _i, _i]),
     "parrot_attn_prefill": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _i, _vp]),
     "parrot_e4_bytes": (_i64, [_i, _i, _i]),

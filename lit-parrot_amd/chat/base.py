@@ -138,8 +138,7 @@ def generate(
     emitted = 0     # steps t whose yield decision has been taken
     while True:
         flag = sess.stop.flag.tolist()  # one device read per chunk
-        if sess.eng is not None:
-            sess.eng.check_error()  # (the stream engine's time-out word: same sync)
+        sess.check_error()  # (the time-out words of the in-launch waits: same sync)
         gen = sess.tokens[T: T + done].to(dtype)
         hit_t, hit_n = flag
         upto = done if hit_t < 0 else hit_t + 1

@@ -100,8 +100,24 @@ constexpr int ENG_MAXQ_BIG = EngCfg<1, 0>::MAXQ, ENG_MAXQ_STD = EngCfg<0, 0>::MA
 constexpr int ENG_NSLOT_BIG = EngCfg<1, 0>::NSLOT, ENG_NSLOT_STD = EngCfg<0, 0>::NSLOT;
 constexpr int ENG_MAXG_E8 = EngCfg<0, PARROT_ENG_W_E8>::MAXG, ENG_MAXG_E8_BIG = EngCfg<1, PARROT_ENG_W_E8>::MAXG;
 constexpr int ENG_GROUP_STRIDE = 272;     // LDS bytes per 128-element group of an activation buffer (256 + 16: bank spread)
-constexpr unsigned ENG_SPINS_LDS = 2000000u;
-constexpr unsigned ENG_SPINS_GLOBAL = 60000u;
+// Every wait is bounded in TIME (the chip-wide 100 MHz clock, s_memrealtime), not in spins: a healthy launch slowed down by
+// a profiler or by a second replica on the same device polls more slowly, it does not wait longer.  The clock is first read
+// at a wait's first checkpoint (64 / 16 polls in), so the waits that pass at once never touch it.
+#ifndef ENG_WAIT_TICKS_V
+#define ENG_WAIT_TICKS_V 50000000ull  // 0.5 s
+#endif
+constexpr uint64_t ENG_WAIT_TICKS = ENG_WAIT_TICKS_V;
+// Diagnostic builds that MEASURE the two halves of the token ("the engine's ceiling"; results are garbage):
+//   ENG_STUB_UNITS = 1    the Linears' units do no arithmetic (slots are awaited and released, blocks published): what is
+//                         left is the stream, the gathers and the hand-offs;
+//   ENG_STUB_HANDOFF = 1  every hand-off is taken as satisfied (whatever the granules hold, from an earlier launch): what is
+//                         left is the stream, the arithmetic and the CU's own barriers.
+#ifndef ENG_STUB_UNITS
+#define ENG_STUB_UNITS 0
+#endif
+#ifndef ENG_STUB_HANDOFF
+#define ENG_STUB_HANDOFF 0
+#endif
 
 typedef parrot_eng_op_t EngOp;
 typedef parrot_eng_state_t EngState;
@@ -129,11 +145,13 @@ template <class CF>
 constexpr int ef_red2() { return EF_RED + ENG_RED * CF::MAXQ * 8 * 4; }  // E8: [ENG_RED][MAXQ][8] float, the units' outlier sums
 template <class CF>
 constexpr int ef_q8() { return ef_red2<CF>() + ENG_RED * CF::MAXQ * 8 * 4; }  // E8: activation quantiser state (EQ_*)
+constexpr int ENG_Q8_STATE = 384;  // bytes of the E8 quantiser state
 template <class CF>
-constexpr int ef_bytes() { return CF::WF == PARROT_ENG_W_E8 ? ef_q8<CF>() + 256 : ef_red2<CF>(); }
+constexpr int ef_bytes() { return CF::WF == PARROT_ENG_W_E8 ? ef_q8<CF>() + ENG_Q8_STATE : ef_red2<CF>(); }
 // LLM.int8 (E8) activation quantiser state, byte offsets from ef_q8(): the waves' |x| maxima and outlier counts of the
-// vector being gathered, then per LDS buffer the row scale (absmax) and the outlier count
-constexpr int EQ_MAX = 0, EQ_CNT = 64, EQ_SA = 128, EQ_NO = 136;
+// vector being gathered - one set per gather round (a second norm of the same input is a second round, and a fast wave may be
+// in it while a slow one still reads the first round's) -, then per LDS buffer the row scale (absmax) and the outlier count
+constexpr int EQ_MAX = 0, EQ_CNT = 64, EQ_SA = 128, EQ_NO = 136, EQ_ROUND2 = 192;  // second round: EQ_MAX / EQ_CNT + EQ_ROUND2
 constexpr int ENG_Q8_CAP = 1024;  // outlier list entries per buffer ({column, fp16 value} in 4 bytes)
 constexpr float ENG_MM_DEQUANT = 6.200012e-05f;  // 1 / (127 * 127), the constant of w8.hip / bitsandbytes' mm_dequant
 __device__ __forceinline__ float eng_rhalf(float v) { return __half2float(__float2half(v)); }
@@ -264,18 +282,34 @@ struct EngCtx {
 };
 
 __device__ __forceinline__ bool eng_aborted(const EngCtx& c) { return lds_ld(c.fx + EF_ABORT) != 0; }
+// A wait gave up (or a check failed): this CU's later waits fall through (EF_ABORT) and the launch's error word takes the
+// code - the FIRST one only (compare-and-swap from 0: what went wrong first is what the host must see; the CUs that give up
+// later, because the first one never published, would overwrite it with their own symptom).  The winner also leaves the code
+// in the host-visible words (pinned host memory, read by the watchdog of bench.py without a HIP call).
 __device__ __forceinline__ void eng_fail(const EngState& st, const EngCtx& c, uint32_t code) {
     lds_st(c.fx + EF_ABORT, 1u);
-    __hip_atomic_store((glb_u32_t*)st.err, code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    uint32_t expected = 0u;
+    if (__hip_atomic_compare_exchange_strong((glb_u32_t*)st.err, &expected, code, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) &&
+        st.host_words != nullptr)
+        __hip_atomic_store((glb_u32_t*)st.host_words, code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+// another CU has failed: stop waiting, keep its code
+__device__ __forceinline__ void eng_abort_local(const EngCtx& c) { lds_st(c.fx + EF_ABORT, 1u); }
+// true once a wait that started polling at (lazily read) t0 has used up its time
+__device__ __forceinline__ bool eng_timed_out(uint64_t& t0) {
+    const uint64_t now = __builtin_amdgcn_s_memrealtime();
+    if (t0 == 0) t0 = now;
+    return now - t0 > ENG_WAIT_TICKS;
 }
 // spin (LDS word >= target), bounded
 __device__ __forceinline__ void eng_wait_lds_ge(const EngState& st, const EngCtx& c, int off, uint32_t target, uint32_t code) {
     unsigned spins = 0;
+    uint64_t t0 = 0;
     while ((int32_t)(lds_ld(c.fx + off) - target) < 0) {
         __builtin_amdgcn_s_sleep(1);
         if ((++spins & 63u) == 0) {
             if (eng_aborted(c)) return;
-            if (spins > ENG_SPINS_LDS) {
+            if (eng_timed_out(t0)) {
                 eng_fail(st, c, code);
                 return;
             }
@@ -287,12 +321,13 @@ __device__ __forceinline__ void eng_wait_lds_ge(const EngState& st, const EngCtx
 template <int MODE>
 __device__ __forceinline__ void eng_wait_lds_ge_tight(const EngState& st, const EngCtx& c, int off, uint32_t target, uint32_t code) {
     unsigned spins = 0;
+    uint64_t t0 = 0;
     if (MODE == 1) __builtin_amdgcn_s_setprio(0);  // the waves still working share this SIMD: they go first
     while ((int32_t)(lds_ld(c.fx + off) - target) < 0) {
         if (MODE == 2) __builtin_amdgcn_s_sleep(1);
         if ((++spins & 255u) == 0) {
             if (eng_aborted(c)) break;
-            if (spins > 4 * ENG_SPINS_LDS) {
+            if (eng_timed_out(t0)) {
                 eng_fail(st, c, code);
                 break;
             }
@@ -598,11 +633,16 @@ __device__ __forceinline__ void eng_stamp(const EngState& st, const EngCtx& c, c
 __device__ __forceinline__ uint32_t eng_gran_wait(const EngState& st, const EngCtx& c, const uint64_t* p, uint64_t v, bool need,
                                                  uint32_t code, unsigned* nspins = nullptr) {
     unsigned spins = 0;
-    while (!__all(!need || (uint32_t)(v >> 32) == c.epoch)) {
+    uint64_t t0 = 0;
+    while (!ENG_STUB_HANDOFF && !__all(!need || (uint32_t)(v >> 32) == c.epoch)) {
         __builtin_amdgcn_s_sleep(ENG_POLL_SLEEP);
         if ((++spins & 15u) == 0) {
             if (eng_aborted(c)) break;
-            if (spins > ENG_SPINS_GLOBAL || ld_err(st) != 0) {
+            if (ld_err(st) != 0) {
+                eng_abort_local(c);
+                break;
+            }
+            if (eng_timed_out(t0)) {
                 eng_fail(st, c, code);
                 break;
             }
@@ -645,8 +685,9 @@ __device__ __forceinline__ void eng_gather(const EngState& st, const EngCtx& c0,
             // half a round trip after it happened instead of a whole one
             const uint64_t* gp = in + (npairs - 1);
             unsigned gs = 0;
+            uint64_t gt0 = 0;
             uint64_t va = ld_gran(gp), vb = 0;
-            for (;;) {
+            for (; !ENG_STUB_HANDOFF;) {
                 if (ENG_GATE_DEEP) vb = ld_gran(gp);
                 if ((uint32_t)(va >> 32) == c.epoch) break;
                 va = ld_gran(gp);
@@ -654,7 +695,11 @@ __device__ __forceinline__ void eng_gather(const EngState& st, const EngCtx& c0,
                 if (!ENG_GATE_DEEP) __builtin_amdgcn_s_sleep(ENG_POLL_SLEEP);
                 if ((++gs & 15u) == 0) {
                     if (eng_aborted(c)) break;
-                    if (gs > ENG_SPINS_GLOBAL || ld_err(st) != 0) {
+                    if (ld_err(st) != 0) {
+                        eng_abort_local(c);
+                        break;
+                    }
+                    if (eng_timed_out(gt0)) {
                         eng_fail(st, c, 0x40000000u | (uint32_t)k);
                         break;
                     }
@@ -667,6 +712,7 @@ __device__ __forceinline__ void eng_gather(const EngState& st, const EngCtx& c0,
         }
         eng_stamp(st, c, w, k, 6);
         unsigned spins = 0;
+        uint64_t st0 = 0;
         for (;;) {
             uint64_t gv[CF::MAXG];
 #pragma unroll
@@ -682,11 +728,15 @@ __device__ __forceinline__ void eng_gather(const EngState& st, const EngCtx& c0,
                 ok = ok && ((uint32_t)(gv[i] >> 32) == c.epoch || pr >= npairs);
                 xv[i] = pr < npairs ? (uint32_t)gv[i] : 0u;
             }
-            if (__all(ok)) break;
+            if (ENG_STUB_HANDOFF || __all(ok)) break;
             __builtin_amdgcn_s_sleep(ENG_POLL_SLEEP);
             if ((++spins & 15u) == 0) {
                 if (eng_aborted(c)) break;
-                if (spins > ENG_SPINS_GLOBAL || ld_err(st) != 0) {
+                if (ld_err(st) != 0) {
+                    eng_abort_local(c);
+                    break;
+                }
+                if (eng_timed_out(st0)) {
                     eng_fail(st, c, 0x41000000u | (uint32_t)k);
                     break;
                 }
@@ -782,9 +832,10 @@ __device__ __forceinline__ void eng_gather(const EngState& st, const EngCtx& c0,
                 }
             }
             mx = wave_max(mx);
+            const int eq_r = second ? EQ_ROUND2 : 0;  // this round's set of the waves' maxima / counts
             if (c.lane == 0) {
-                reinterpret_cast<float*>(q8 + EQ_MAX)[w.cw] = mx;
-                reinterpret_cast<int*>(q8 + EQ_CNT)[w.cw] = cnt;
+                reinterpret_cast<float*>(q8 + eq_r + EQ_MAX)[w.cw] = mx;
+                reinterpret_cast<int*>(q8 + eq_r + EQ_CNT)[w.cw] = cnt;
             }
             if (na.kind != 0) {
                 eng_release<CF>(c, w.seq);
@@ -795,10 +846,10 @@ __device__ __forceinline__ void eng_gather(const EngState& st, const EngCtx& c0,
             int base = 0, total = 0;
             mx = 0.f;
             for (int t = 0; t < CF::NC; ++t) {
-                const int ct = reinterpret_cast<const int*>(q8 + EQ_CNT)[t];
+                const int ct = reinterpret_cast<const int*>(q8 + eq_r + EQ_CNT)[t];
                 if (t < w.cw) base += ct;
                 total += ct;
-                mx = fmaxf(mx, reinterpret_cast<const float*>(q8 + EQ_MAX)[t]);
+                mx = fmaxf(mx, reinterpret_cast<const float*>(q8 + eq_r + EQ_MAX)[t]);
             }
             const float inv = mx > 0.f ? __fdiv_rn(127.0f, mx) : 0.f;
             uint32_t* olist = reinterpret_cast<uint32_t*>(dstb + op->nq * 2048);
@@ -891,6 +942,9 @@ __device__ __forceinline__ void eng_gemv(const EngState& st, const EngCtx& c0, E
     const int epi = op->epilogue;
     const bool has_bias = !e8 && op->bias != nullptr;  // (E8: that field holds the rows' scales)
     const int total = nb * nq;
+    // a K-chunk op keeps its rows' running sums in result slot MAXQ - 1 of the rows' 8 block buffers: the chunk must leave that
+    // slot free and the CU must own at most 8 blocks (the host builds the table that way; a table that does not is refused here)
+    if (op->acc != 0 && (nq >= MAXQ || nb > 8) && w.cw == 0 && c.lane == 0) eng_fail(st, c, 0x71000000u | (uint32_t)k);
     // units are dealt round-robin over the consumer waves: wave cw takes units cw, cw + NC, ...; (bl, Q) = (local block,
     // unit of the row) are stepped without a division per unit
     int bl = w.cw / nq, Q = w.cw - bl * nq;
@@ -980,6 +1034,8 @@ __device__ __forceinline__ void eng_gemv(const EngState& st, const EngCtx& c0, E
             }
             v = p0 + p1;
             if (Q == 0 && has_bias && c.lane < 8) redb[rb * 8 + c.lane] = bf2f(*reinterpret_cast<const bf16_t*>(slot + ENG_META_OFF + c.lane * 2));
+        } else if (ENG_STUB_UNITS) {
+            v = 0.f;  // (diagnostic build: no arithmetic, the slot is only awaited and released)
         } else {
             const int qq = Q & 3;
             const uint32_t mt = *reinterpret_cast<const uint32_t*>(slot + ENG_META_OFF + (qq * 64 + c.lane) * 4);
@@ -1325,6 +1381,7 @@ __device__ __forceinline__ void eng_attn_combine(const EngState& st, const EngCt
             eng_wait_lds_ge(st, c, EF_GATE2, (uint32_t)(k + 1), 0x55000000u | (uint32_t)k);
         }
         unsigned spins = 0;
+        uint64_t ct0 = 0;
         for (; ky.ns > 1;) {  // flat sweep: every load in flight at once, repeated until every tag matches
             uint64_t gv[NPW];
 #pragma unroll
@@ -1336,11 +1393,15 @@ __device__ __forceinline__ void eng_attn_combine(const EngState& st, const EngCt
                 ok = ok && ((uint32_t)(gv[t] >> 32) == c.epoch || i >= cnt);
                 if (i < cnt) stage[i] = __uint_as_float((uint32_t)gv[t]);
             }
-            if (__all(ok)) break;
+            if (ENG_STUB_HANDOFF || __all(ok)) break;
             __builtin_amdgcn_s_sleep(ENG_POLL_SLEEP);
             if ((++spins & 15u) == 0) {
                 if (eng_aborted(c)) break;
-                if (spins > ENG_SPINS_GLOBAL || ld_err(st) != 0) {
+                if (ld_err(st) != 0) {
+                    eng_abort_local(c);
+                    break;
+                }
+                if (eng_timed_out(ct0)) {
                     eng_fail(st, c, 0x51000000u | (uint32_t)k);
                     break;
                 }
@@ -1410,7 +1471,10 @@ __device__ __forceinline__ void eng_consumer(const EngState& st, const EngCtx& c
             eng_attn<CF, HS, HQ>(st, c, w, op, k);
     }
     if (!st.greedy) {
-        if (c.cu == 0 && cw == 0 && c.lane == 0) st.epoch[0] = c.epoch + 1;
+        if (c.cu == 0 && cw == 0 && c.lane == 0) {
+            st.epoch[0] = c.epoch + 1;
+            if (st.host_words != nullptr) __hip_atomic_store((glb_u32_t*)(st.host_words + 1), c.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
         return;
     }
     // ---- greedy sampling: the CU's arg-max candidate -> CU 0 -> tokens[pos + 1], pos += 1
@@ -1472,6 +1536,8 @@ __device__ __forceinline__ void eng_consumer(const EngState& st, const EngCtx& c
         st.tokens[c.pos + 1] = (bi == 0x7fffffff) ? 0 : bi;
         st.pos[0] = c.pos + 1;
         st.epoch[0] = c.epoch + 1;
+        // progress word for a host watchdog: the epoch of the last launch that ran to its end
+        if (st.host_words != nullptr) __hip_atomic_store((glb_u32_t*)(st.host_words + 1), c.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
 
@@ -1720,7 +1786,7 @@ static int64_t eng_pick_build(int kmax, int wfmt, int buf0_bytes, int buf1_bytes
     // (int8: units of 2048 columns; the narrow build gathers up to 14 * 7 groups of 128 = 12544 columns, the wide one 22528)
     for (int b = (e8 ? ((kmax + 2047) / 2048) * 16 > (16 - ENG_NLOAD_MULTI) * ENG_MAXG_E8 : eng_is_big(kmax)) ? 1 : 0; b < 2; ++b) {
         const int nslot = e16 ? (b ? EngCfg<1, PARROT_ENG_W_E16>::NSLOT : EngCfg<0, PARROT_ENG_W_E16>::NSLOT) : (b ? ENG_NSLOT_BIG : ENG_NSLOT_STD);
-        lds = (int64_t)nslot * ENG_SLOT_BYTES + buf0_bytes + buf1_bytes + EF_RED + ENG_RED * (b ? ENG_MAXQ_BIG : ENG_MAXQ_STD) * 32 * (e8 ? 2 : 1) + (e8 ? 256 : 0);
+        lds = (int64_t)nslot * ENG_SLOT_BYTES + buf0_bytes + buf1_bytes + EF_RED + ENG_RED * (b ? ENG_MAXQ_BIG : ENG_MAXQ_STD) * 32 * (e8 ? 2 : 1) + (e8 ? ENG_Q8_STATE : 0);
         *big = b != 0;
         if (lds <= 160 * 1024) break;
     }

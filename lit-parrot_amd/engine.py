@@ -378,6 +378,10 @@ class StreamEngine:
         st.wfmt = self._state_wfmt(c, ops_list[0].wfmt)
         st.lds_buf0_bytes, st.lds_buf1_bytes, st.attn_buf = self._lds_buffers(c, wfmt)
         st.arg = self.granules.data_ptr() + 8 * L * per_layer
+        # two words of pinned host memory the kernel can write: [0] the first error code, [1] the epoch of the last launch that
+        # ran to its end.  A host watchdog (bench.py) reads them while a launch is stuck, without any HIP call.
+        self.host_words = torch.zeros((2,), dtype=torch.int32).pin_memory()
+        st.host_words = self.host_words.data_ptr()
         self.state = st
         self.n_ops = len(ops_list)
         self.dbg = None
@@ -395,8 +399,22 @@ class StreamEngine:
         check(self.lib.parrot_eng_step(C.byref(self.state), _hip.stream()), "parrot_eng_step")
         return self.logits
 
+    ERROR_KINDS = {1: "loader: a ring slot was never released", 2: "consumer barrier", 3: "a ring slot never landed",
+                   4: "hand-off of a Linear's input (0x40: gate, 0x41: sweep, 0x42: waves behind the gate)",
+                   5: "attention hand-off (0x50 QKV rows, 0x51 partial states)", 6: "arg-max hand-off",
+                   7: "table check (0x70 more LLM.int8 outliers than the list holds, 0x71 K-chunk op outside its limits)"}
+
     def check_error(self) -> None:
-        """Host-side check of the kernel's time-out word (syncs)."""
+        """Host-side check of the kernel's error word (syncs): the code of the FIRST wait that gave up or check that failed.
+        The word is sticky - every later launch falls through its waits and decodes garbage - so it is cleared here and
+        the caller must start over."""
         e = int(self.err.item()) & 0xFFFFFFFF
         if e:
-            raise ParrotHipError(f"stream engine: a bounded wait gave up, error word {e:#x}")
+            self.err.zero_()
+            self.host_words.zero_()
+            kind = self.ERROR_KINDS.get(e >> 28, "?")
+            raise ParrotHipError(f"stream engine: a bounded wait gave up, first error word {e:#x} ({kind}; low bits: op index or ring sequence number)")
+
+    def progress(self) -> tuple:
+        """(first error code, epoch of the last completed launch) from the pinned host words: no HIP call, safe from a watchdog thread."""
+        return int(self.host_words[0]) & 0xFFFFFFFF, int(self.host_words[1]) & 0xFFFFFFFF

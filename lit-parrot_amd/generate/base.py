@@ -110,6 +110,17 @@ class DecodeSession:
             self._step()
         return self.eng.logits[0] if self.eng is not None else self.ws.logits[0]
 
+    def check_error(self) -> None:
+        """Host-side check (syncs) of the in-launch waits of either executor: the stream engine's error word, and the
+        time-out word of the attention + out-projection launch of the multi-launch step.  A step that gave up decoded
+        garbage: fail loudly, never report its tokens or its speed."""
+        if self.eng is not None:
+            self.eng.check_error()
+        if int(self.ws.ap_sync[2].item()) != 0:
+            self.ws.ap_sync.zero_()
+            raise ParrotHipError("attention + out-projection launch: the wait for the heads timed out (workgroups of the launch "
+                                 "not resident together?); set lit_parrot_amd.ops.FUSE_ATTN_PROJ = False to use two launches")
+
 
 # The one-launch stream engine (engine.py) for the models it is built for (Llama-2 7B family, int4 g128).  Measured on
 # Llama-2-7B int4 (DESIGN.md §8): its token time barely moves with the context (K/V rows stream through the same LDS ring
@@ -191,6 +202,5 @@ def generate(
     else:
         i = n_new
     out = sess.tokens[: T + i].to(dtype).clone()
-    if sess.eng is not None:
-        sess.eng.check_error()  # a bounded wait of the one-launch step gave up (e.g. fewer CUs than workgroups): fail loudly
+    sess.check_error()  # a bounded in-launch wait gave up (e.g. fewer CUs than resident workgroups): fail loudly
     return out
