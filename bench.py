@@ -83,16 +83,13 @@ def token_bytes(cfg, mode, context):
     return weights, kv + cfg.n_embd * 2
 
 
-def kernel_bytes_per_token(cfg, mode, fused_attn_proj: bool = False):
-    """Algorithmic bytes handled by each kernel id of the library during one token (for the roofline object).
-    ``fused_attn_proj``: the out-projection's bytes belong to the attention + projection launch, not to a GEMV launch."""
+def kernel_bytes_per_token(cfg, mode):
+    """Algorithmic bytes handled by each kernel id of the library during one token (for the roofline object)."""
     lb = linear_bytes(cfg, mode)
     L = cfg.n_layer
     prefix = {None: "bf16_gemv", "bnb.int8": "w8_gemv"}.get(mode, "w4c_gemv" if (mode or "").startswith(("bnb.nf4", "bnb.fp4")) else "w4_gemv")
-    single = [k for k in lb if k not in ("mlp.fc_1", "mlp.fc_2", "lm_head") and not (fused_attn_proj and k == "attn.proj")]
+    single = [k for k in lb if k not in ("mlp.fc_1", "mlp.fc_2", "lm_head")]
     res = {prefix: (sum(lb[k] for k in single) * L + lb["lm_head"], len(single) * L + 1)}
-    if fused_attn_proj:
-        res["attn_proj_w4"] = (lb["attn.proj"] * L, L)  # (+ the K/V rows of the context, a few % at the bench's windows)
     if "mlp.fc_1" in lb:
         dual = prefix if mode == "bnb.int8" else prefix + "_dual"
         b, n = res.get(dual, (0, 0))
@@ -100,7 +97,7 @@ def kernel_bytes_per_token(cfg, mode, fused_attn_proj: bool = False):
     return res  # {kernel name: (bytes per token, launches per token)}
 
 
-PMC_KERNEL_PREFIX = {"w4_gemv": "w4_gemv_kernel<1, false", "w4_gemv_dual": "w4_gemv_kernel<1, true", "attn_proj_w4": "attn_proj_w4_kernel",
+PMC_KERNEL_PREFIX = {"w4_gemv": "w4_gemv_kernel<1, false", "w4_gemv_dual": "w4_gemv_kernel<1, true",
                      "bf16_gemv": "bf16_gemv_kernel<1, false", "bf16_gemv_dual": "bf16_gemv_kernel<1, true",
                      "w8_gemv": "w8_gemv_kernel", "attn_fused_decode": "attn_fused_decode_kernel", "eng_token": "eng_token_kernel"}
 
@@ -355,7 +352,6 @@ def main() -> None:
     ap.add_argument("--devices", default="", help="comma list of HIP_VISIBLE_DEVICES values for the replicas spawned by --gpus N (default 0..N-1)")
     ap.add_argument("--attn-split-keys", type=int, default=0, help="A/B: window slots per sequence split of the decode attention (default: the library's)")
     ap.add_argument("--engine", type=int, default=-1, help="1 / 0: force the one-launch stream engine on / off (default: the library's choice)")
-    ap.add_argument("--fuse-attn-proj", type=int, default=-1, help="A/B: 1 / 0 attention + out-projection of the multi-launch step in one launch / two (default: the library's)")
     ap.add_argument("--watchdog", type=float, default=300.0, help="seconds without a phase change before the run reports where it is stuck and exits 3 (0: off)")
     args = ap.parse_args()
 
@@ -395,10 +391,6 @@ def main() -> None:
         from lit_parrot_amd import ops as _ops
 
         _ops.ATTN_SPLIT_KEYS = args.attn_split_keys
-    if args.fuse_attn_proj >= 0:
-        from lit_parrot_amd import ops as _ops
-
-        _ops.FUSE_ATTN_PROJ = bool(args.fuse_attn_proj)
     wd = Watchdog(args.watchdog, tag=f"bench.py[{rank}]")
     cfg_name, mode, T, dtype_label = WORKLOADS[args.workload]
     cfg = Config.from_name(cfg_name)
@@ -462,7 +454,7 @@ def main() -> None:
     ms_per_step = elapsed_max / args.steps * 1e3
     ctx_mean = T + args.warmup + args.steps / 2.0
     w_bytes, kv_bytes = token_bytes(cfg, mode, ctx_mean)
-    kb = kernel_bytes_per_token(cfg, mode, "attn_proj_w4" in stats)
+    kb = kernel_bytes_per_token(cfg, mode)
     kb["eng_token"] = (w_bytes + kv_bytes, 1)  # the stream engine: the whole token is one launch
     dom = max(stats, key=lambda k: stats[k][0])
     kernels = {k: {"avg_us": v[0] / v[1] * 1e3, "launches_per_token": v[1] / prof_steps, "ms_per_token": v[0] / prof_steps}
@@ -514,7 +506,6 @@ def main() -> None:
                              "frac": prefill_flops / t_pre / 1e12 / MFMA_BF16_PEAK_TFLOPS, "linear_flops": prefill_flops},
         "build_s": t_build,
         "engine": sess.eng is not None,
-        "fused_attn_proj": bool(sess.eng is None and "attn_proj_w4" in stats),
     }
     if replica is not None:  # the parent aggregates: it needs this replica's own clock
         result.update(elapsed_s=elapsed, device=os.environ.get("HIP_VISIBLE_DEVICES", "?"), cpu_baseline=None)

@@ -201,21 +201,6 @@ int parrot_attn_fused_decode(const void* qkv, const void* rope_cos, const void* 
                              const int32_t* pos, int n_groups, int q_per_kv, int hs, int S, int nsplit,
                              void* workspace, void* tickets, void* k_cache, void* v_cache, void* y,
                              void* stream);
-/* The same decode step of CausalSelfAttention AND the int4 out-projection with its residual add behind it in ONE launch
- * (lit_gpt/model.py:208-254 followed by :171 / :178-179 `x = x + proj(y)`; the Linear is ColBlockQuantizedLinear.forward,
- * quantize/gptq.py:254-264): the projection's workgroups stream their W4K rows into registers while the attention runs and
- * take the heads over inside the launch.  Whole window in one workgroup per (group, chunk of query heads): windows the caller
- * would split (parrot_attn_fused_decode with nsplit > 1) keep the two-launch path.
- * heads: [n_head*hs] bf16 scratch that ONLY this entry point touches (it is handed over between workgroups with write-through
- * stores / L1-bypassing loads); packed: W4K image of the (N, n_head*hs) projection; bias: bf16 [N] or NULL; residual: bf16 [N]
- * or NULL (may alias out); sync4: four zero-initialised uint32 (arrival counters, re-armed by the kernel; word 2 is set when
- * the in-launch wait timed out: the caller must treat the step as failed and zero the words);
- * max_workgroups: workgroups of 1024 threads that are resident at once on the device (its CU count): the launch never
- * holds more, else PARROT_EUNSUPPORTED.                                                                                      */
-int parrot_attn_proj_w4(const void* qkv, const void* rope_cos, const void* rope_sin, int n_elem, const int32_t* pos,
-                        int n_groups, int q_per_kv, int hs, int S, void* k_cache, void* v_cache, void* heads,
-                        const void* packed, const void* bias, const void* residual, void* out, int N, int group,
-                        void* sync4, int max_workgroups, void* stream);
 /* ---- small ops of the step ----------------------------------------------------------
  * x[m] = wte[tokens[(pos ? *pos : 0) + m]]   (lit_gpt/model.py:99)                    */
 int parrot_embedding(const void* wte, int d, const int64_t* tokens, const int32_t* pos, int M,

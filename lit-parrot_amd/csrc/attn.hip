@@ -16,7 +16,6 @@
 #include <hip/hip_fp16.h>
 
 #include "parrot_common.h"
-#include "w4_plan.h"
 
 namespace parrot {
 
@@ -279,16 +278,13 @@ static unsigned long long* g_attn_dbg_host = nullptr;  // diagnostic build only:
 static constexpr unsigned long long* g_attn_dbg_host = nullptr;
 #endif
 
-// The body of the launch for workgroup (group g, split, chunk zc of nz chunks of the group's query heads).  YSYNC: the heads
-// are handed to OTHER workgroups of the same launch (attn_proj_w4_kernel below): they leave with write-through (agent-scope)
-// stores, one whole 128-byte line per wave instruction (nsplit must be 1).
-template <int HS, int HQ, int WAVES, bool YSYNC>
-__device__ __forceinline__ void
-attn_fused_body(const bf16_t* __restrict__ qkv, const __half* __restrict__ rope_cos,
-                const __half* __restrict__ rope_sin, int n_elem, const int32_t* __restrict__ pos_ptr,
-                bf16_t* __restrict__ k_cache, bf16_t* __restrict__ v_cache, int n_groups, int q_per_kv, int S,
-                int nsplit, float* __restrict__ ws, unsigned int* __restrict__ tickets, bf16_t* __restrict__ y,
-                unsigned long long* dbg, const int g, const int split, const int zc, const int nz) {
+template <int HS, int HQ, int WAVES>
+__global__ void __launch_bounds__(WAVES * 64)
+attn_fused_decode_kernel(const bf16_t* __restrict__ qkv, const __half* __restrict__ rope_cos,
+                         const __half* __restrict__ rope_sin, int n_elem, const int32_t* __restrict__ pos_ptr,
+                         bf16_t* __restrict__ k_cache, bf16_t* __restrict__ v_cache, int n_groups, int q_per_kv, int S,
+                         int nsplit, float* __restrict__ ws, unsigned int* __restrict__ tickets, bf16_t* __restrict__ y,
+                         unsigned long long* dbg) {
     constexpr int LPR = HS / 8;
     constexpr int RPW = 64 / LPR;
     attn_stamp(dbg, 0);
@@ -298,7 +294,8 @@ attn_fused_body(const bf16_t* __restrict__ qkv, const __half* __restrict__ rope_
     __shared__ __attribute__((aligned(16))) bf16_t sh_kv[2][HS];  // roped k_new, v_new as stored in the cache
     __shared__ int sh_last;
 
-    const int h0 = zc * HQ;  // this workgroup's chunk of the group's query heads (GQA: chunks run in parallel)
+    const int g = blockIdx.x, split = blockIdx.y;
+    const int h0 = blockIdx.z * HQ;  // this workgroup's chunk of the group's query heads (GQA: chunks run in parallel)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int sub = lane / LPR, dl = lane % LPR;
     const int n_head = n_groups * q_per_kv;
@@ -359,7 +356,7 @@ attn_fused_body(const bf16_t* __restrict__ qkv, const __half* __restrict__ rope_
     __syncthreads();
     attn_stamp(dbg, 1);
     // ---- KV append by the workgroup that owns the new slot
-    if (zc == 0 && slot_new >= s_begin && slot_new < s_begin + per && threadIdx.x < 2 * LPR) {
+    if (blockIdx.z == 0 && slot_new >= s_begin && slot_new < s_begin + per && threadIdx.x < 2 * LPR) {
         const int which = threadIdx.x / LPR, c = threadIdx.x % LPR;
         bf16_t* dst = (which ? v_cache : k_cache) + ((int64_t)g * S + slot_new) * HS;
         reinterpret_cast<uint4*>(dst)[c] = reinterpret_cast<const uint4*>(sh_kv[which])[c];
@@ -464,10 +461,7 @@ attn_fused_body(const bf16_t* __restrict__ qkv, const __half* __restrict__ rope_
                 }
                 const int head = g * q_per_kv + h0 + hh;
                 if (nsplit == 1) {
-                    if (YSYNC)
-                        __hip_atomic_store(y + (int64_t)head * HS + d, f2bf(a / l), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    else
-                        y[(int64_t)head * HS + d] = f2bf(a / l);
+                    y[(int64_t)head * HS + d] = f2bf(a / l);
                 } else {
                     float* p = ws + ((int64_t)head * nsplit + split) * (HS + 2);
                     store_agent(p + d, a);
@@ -485,9 +479,9 @@ attn_fused_body(const bf16_t* __restrict__ qkv, const __half* __restrict__ rope_
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every storing wave drains its write-through stores
     __syncthreads();
     if (threadIdx.x == 0) {
-        const unsigned int t = __hip_atomic_fetch_add(&tickets[g * nz + zc], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned int t = __hip_atomic_fetch_add(&tickets[g * gridDim.z + blockIdx.z], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         sh_last = (t == (unsigned int)(nsplit - 1));
-        if (sh_last) __hip_atomic_store(&tickets[g * nz + zc], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // re-arm
+        if (sh_last) __hip_atomic_store(&tickets[g * gridDim.z + blockIdx.z], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // re-arm
     }
     __syncthreads();
     if (!sh_last) return;
@@ -506,120 +500,6 @@ attn_fused_body(const bf16_t* __restrict__ qkv, const __half* __restrict__ rope_
             a += load_agent(p + t * (HS + 2) + d) * wgt;
         }
         y[(int64_t)head * HS + d] = f2bf(a / l);
-    }
-}
-
-template <int HS, int HQ, int WAVES>
-__global__ void __launch_bounds__(WAVES * 64)
-attn_fused_decode_kernel(const bf16_t* __restrict__ qkv, const __half* __restrict__ rope_cos,
-                         const __half* __restrict__ rope_sin, int n_elem, const int32_t* __restrict__ pos_ptr,
-                         bf16_t* __restrict__ k_cache, bf16_t* __restrict__ v_cache, int n_groups, int q_per_kv, int S,
-                         int nsplit, float* __restrict__ ws, unsigned int* __restrict__ tickets, bf16_t* __restrict__ y,
-                         unsigned long long* dbg) {
-    attn_fused_body<HS, HQ, WAVES, false>(qkv, rope_cos, rope_sin, n_elem, pos_ptr, k_cache, v_cache, n_groups, q_per_kv, S, nsplit, ws,
-                                          tickets, y, dbg, blockIdx.x, blockIdx.y, blockIdx.z, gridDim.z);
-}
-
-// ------------------------------------------------------------------------------------------ decode attention + out-projection
-// ONE launch for [split + RoPE + KV append + attention] and the int4 out-projection with its residual add behind it
-// (lit_gpt/model.py:208-254 and :171 / :178).  The attention of a single token keeps n_groups * nz workgroups busy for ~3 us with
-// the HBM idle, and the projection that follows used to pay its own boundary, ramp and tail (4.9 us for 8.9 MB on Llama-2-7B).
-// Here the projection's workgroups belong to the same launch: they request ALL their weight rows at once (they fit the
-// registers: RU rows x 16 bytes per lane), so that stream runs beside the attention, then wait for the heads and only have
-// the arithmetic, the slab sums and the epilogue left.
-//   * workgroups 0 .. n_attn - 1: the fused decode attention (nsplit = 1: the whole window, 16 waves); the heads leave with
-//     write-through stores, every storing wave drains them (vmcnt(0)), barrier, ONE agent-scope add on sync[0];
-//   * the others: 16 waves = the matrix's K-slabs x row groups of RU rows.  One lane polls sync[0] (L1-bypassing loads) until
-//     all n_attn attention workgroups have arrived, a barrier, then every lane fetches its 32 head values with
-//     L1-bypassing loads (the heads buffer is only ever touched by this kernel, with such accesses: the guide's
-//     "agent-scope adds / sc1 poll / barrier / sc1 loads" hand-off).  The last projection workgroup to pass the poll re-arms
-//     both counters for the next launch;
-//   * the launch holds at most as many workgroups as the device has CUs and a 1024-thread workgroup always finds room on an
-//     idle CU, so every workgroup is resident and the waiting ones cannot keep the attention out.  The wait is bounded all the
-//     same (0.5 s of the 100 MHz clock): on a time-out sync[2] is set, the launch drains and the host raises.
-template <int HS, int HQ, int RU>
-__global__ void __launch_bounds__(1024)
-attn_proj_w4_kernel(const bf16_t* __restrict__ qkv, const __half* __restrict__ rope_cos, const __half* __restrict__ rope_sin, int n_elem,
-                    const int32_t* __restrict__ pos_ptr, bf16_t* __restrict__ k_cache, bf16_t* __restrict__ v_cache, int n_groups,
-                    int q_per_kv, int S, bf16_t* heads, int n_attn, int nz, const uint4* __restrict__ W,
-                    const bf16_t* __restrict__ bias, const bf16_t* residual, bf16_t* out, int N, int wps, int epi, W4Plan plan,
-                    unsigned int* sync) {
-    if ((int)blockIdx.x < n_attn) {
-        attn_fused_body<HS, HQ, 16, true>(qkv, rope_cos, rope_sin, n_elem, pos_ptr, k_cache, v_cache, n_groups, q_per_kv, S, 1, nullptr,
-                                          nullptr, heads, nullptr, (int)blockIdx.x / nz, 0, (int)blockIdx.x % nz, nz);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // every storing wave: its write-through stores have left
-        __syncthreads();
-        if (threadIdx.x == 0) __hip_atomic_fetch_add(&sync[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        return;
-    }
-    __shared__ float red[16][8];
-    const int b = (int)blockIdx.x - n_attn, nproj = (int)gridDim.x - n_attn;
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const bool wact = wave < plan.nslabs * wps;  // (16 waves need not be a multiple of the slab count)
-    const int slab = wact ? wave / wps : 0, j = wact ? wave % wps : 0;
-    const W4Slab sl = plan.slab[slab];
-    const bool active = wact && lane < sl.nslices;
-    const int lslice = lane < sl.nslices ? lane : sl.nslices - 1;
-    const int gslice = sl.slice0 + lslice;
-    const int gl = gslice / plan.Gs - sl.g0;
-    const int R = wps * RU;
-    const int row0 = b * R + j * RU;
-    // the whole share of the matrix at once: nothing else of this workgroup is waiting behind these requests
-    uint4 w[RU];
-    uint32_t mt[RU];
-#pragma unroll
-    for (int u = 0; u < RU; ++u) {
-        const uint4* rec = W + (int64_t)min(row0 + u, N - 1) * plan.row16;
-        w[u] = load_nt16(rec + sl.w_off16 + lslice);
-        mt[u] = load_nt4(reinterpret_cast<const uint32_t*>(rec + sl.meta_off16) + gl);
-    }
-    const int e_col = min(b * R + (int)threadIdx.x, N - 1);
-    const bf16_t e_res = residual != nullptr ? residual[e_col] : (bf16_t)0;
-    const bf16_t e_bias = bias != nullptr ? bias[e_col] : (bf16_t)0;
-    if (threadIdx.x == 0) {
-        const uint64_t t0 = __builtin_amdgcn_s_memrealtime();
-        while (ld_agent32(&sync[0]) != (unsigned int)n_attn) {
-            __builtin_amdgcn_s_sleep(4);
-            if (__builtin_amdgcn_s_memrealtime() - t0 > 50000000ull) {
-                __hip_atomic_store(&sync[2], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                break;
-            }
-        }
-        const unsigned int t = __hip_atomic_fetch_add(&sync[1], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (t == (unsigned int)(nproj - 1)) {  // everybody has seen the heads: re-arm for the next launch
-            __hip_atomic_store(&sync[0], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(&sync[1], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-    }
-    __syncthreads();
-    uint32_t xr[16];
-    const uint32_t* hp = reinterpret_cast<const uint32_t*>(heads) + (int64_t)gslice * 16;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) xr[i] = ld_agent32(hp + i);
-    float xs = 0.f;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) {
-        if (!active) xr[i] = 0u;
-        xs += bflo(xr[i]) + bfhi(xr[i]);
-    }
-    float lanep[8];
-#pragma unroll
-    for (int u = 0; u < 8; ++u) {
-        lanep[u] = 0.f;
-        if (u < RU) lanep[u] = bflo(mt[u]) * (w4_slice_dot(w[u], xr) - (128.0f + bfhi(mt[u])) * xs);
-    }
-    const float tot = wave_sum8(lanep);  // row u's sum in lanes 8u .. 8u + 7
-    if ((lane & 7) == 0 && (lane >> 3) < RU) red[wave][lane >> 3] = tot;
-    __syncthreads();
-    if ((int)threadIdx.x < R) {
-        const int jj = threadIdx.x / RU, u = threadIdx.x % RU;
-        const int col = b * R + (int)threadIdx.x;
-        if (col < N) {
-            float a0 = 0.f;
-            for (int c = 0; c < plan.nslabs; ++c) a0 += red[c * wps + jj][u];
-            out[col] = apply_epilogue_vals(epi, a0, 0.f, bias != nullptr, bf2f(e_bias), bf2f(e_res));
-        }
     }
 }
 
@@ -717,55 +597,6 @@ int parrot_attn_fused_decode(const void* qkv, const void* rope_cos, const void* 
     }
     set_error("attn_fused_decode: head size %d not built (32, 64, 128)", hs);
     return PARROT_EUNSUPPORTED;
-}
-
-int parrot_attn_proj_w4(const void* qkv, const void* rope_cos, const void* rope_sin, int n_elem, const int32_t* pos, int n_groups,
-                        int q_per_kv, int hs, int S, void* k_cache, void* v_cache, void* heads, const void* packed, const void* bias,
-                        const void* residual, void* out, int N, int group, void* sync4, int max_workgroups, void* stream) {
-    PARROT_REQUIRE(qkv && pos && k_cache && v_cache && heads && packed && out && sync4, "attn_proj_w4: null pointer");
-    PARROT_REQUIRE(n_groups >= 1 && q_per_kv >= 1 && S >= 1 && N >= 1, "attn_proj_w4: bad shape");
-    PARROT_UNSUPPORTED(q_per_kv <= kFusedMaxQ, "attn_proj_w4: at most %d query heads per group (got %d)", kFusedMaxQ, q_per_kv);
-    PARROT_UNSUPPORTED(hs == 64 || hs == 128, "attn_proj_w4: head size %d not built (64, 128)", hs);
-    PARROT_REQUIRE(n_elem % 2 == 0 && n_elem >= 0 && n_elem <= hs, "attn_proj_w4: bad n_elem=%d", n_elem);
-    PARROT_REQUIRE(n_elem == 0 || (rope_cos && rope_sin), "attn_proj_w4: rope tables missing");
-    PARROT_REQUIRE(aligned16(qkv) && aligned16(k_cache) && aligned16(v_cache) && aligned16(packed) && aligned16(heads),
-                   "attn_proj_w4: 16-byte alignment");
-    const int K = n_groups * q_per_kv * hs;
-    W4Plan plan;
-    const int rc = w4_make_plan(N, K, group, &plan);
-    if (rc != PARROT_OK) return rc;
-    const int hq = q_per_kv == 1 ? 1 : (q_per_kv == 2 ? 2 : 4);
-    const int nz = (q_per_kv + hq - 1) / hq, n_attn = n_groups * nz;
-    const int wps = 16 / plan.nslabs;
-    // rows per wave: as few as leave every workgroup of the launch resident at once (one 1024-thread workgroup per CU)
-    int ru = 4;
-    if ((N + wps * ru - 1) / (wps * ru) + n_attn > max_workgroups) ru = 8;
-    const int nproj = (N + wps * ru - 1) / (wps * ru);
-    PARROT_UNSUPPORTED(max_workgroups >= 1 && nproj + n_attn <= max_workgroups,
-                       "attn_proj_w4: %d + %d workgroups do not fit the %d that are resident at once", n_attn, nproj, max_workgroups);
-    const int epi = residual != nullptr ? PARROT_EPI_RESIDUAL : PARROT_EPI_NONE;
-    const dim3 grid(n_attn + nproj), block(1024);
-    hipStream_t st = (hipStream_t)stream;
-#define PARROT_AP_GO(HSV, HQV, RUV)                                                                                               \
-    return launch(K_ATTN_PROJ, attn_proj_w4_kernel<HSV, HQV, RUV>, grid, block, 0, st, (const bf16_t*)qkv, (const __half*)rope_cos,  \
-                  (const __half*)rope_sin, n_elem, pos, (bf16_t*)k_cache, (bf16_t*)v_cache, n_groups, q_per_kv, S, (bf16_t*)heads, \
-                  n_attn, nz, (const uint4*)packed, (const bf16_t*)bias, (const bf16_t*)residual, (bf16_t*)out, N, wps, epi, plan, \
-                  (unsigned int*)sync4)
-#define PARROT_AP_GO2(HSV, HQV)        \
-    do {                               \
-        if (ru == 4) PARROT_AP_GO(HSV, HQV, 4); \
-        PARROT_AP_GO(HSV, HQV, 8);     \
-    } while (0)
-    if (hs == 128) {
-        if (hq == 1) PARROT_AP_GO2(128, 1);
-        if (hq == 2) PARROT_AP_GO2(128, 2);
-        PARROT_AP_GO2(128, 4);
-    }
-    if (hq == 1) PARROT_AP_GO2(64, 1);
-    if (hq == 2) PARROT_AP_GO2(64, 2);
-    PARROT_AP_GO2(64, 4);
-#undef PARROT_AP_GO2
-#undef PARROT_AP_GO
 }
 
 int64_t parrot_attn_workspace_floats(int M, int n_head, int hs, int nsplit) {

@@ -32,7 +32,7 @@ static const char* const kNames[K_COUNT] = {
     "w4_gemv",      "w4_gemv_dual", "w4_repack",  "bf16_gemv",   "bf16_gemv_dual", "w8_quantize_rows",
     "w8_prep_act",  "w8_gemv",      "rmsnorm",    "layernorm",   "rope_kvappend",  "attn_decode",
     "attn_combine", "embedding",    "argmax_advance", "w4_gemm", "bf16_gemm", "attn_fused_decode", "eng_token", "e4_repack", "stop_check", "gptq_block",
-    "w4c_gemv", "w4c_gemv_dual", "w4c_dequant", "gemm_xsum", "gemm_splitk_epilogue", "w4c_gemm", "attn_prefill_vt", "attn_prefill", "w8_gemm", "w8_dequant_epilogue", "w8_outlier", "attn_proj_w4", "topk_sample"};
+    "w4c_gemv", "w4c_gemv_dual", "w4c_dequant", "gemm_xsum", "gemm_splitk_epilogue", "w4c_gemm", "attn_prefill_vt", "attn_prefill", "w8_gemm", "w8_dequant_epilogue", "w8_outlier", "topk_sample"};
 
 }  // namespace parrot
 

@@ -92,7 +92,6 @@ enum KernelId : int {
     K_W8_GEMM,
     K_W8_DEQUANT,
     K_W8_OUTLIER,
-    K_ATTN_PROJ,
     K_TOPK_SAMPLE,
     K_COUNT
 };

@@ -111,15 +111,10 @@ class DecodeSession:
         return self.eng.logits[0] if self.eng is not None else self.ws.logits[0]
 
     def check_error(self) -> None:
-        """Host-side check (syncs) of the in-launch waits of either executor: the stream engine's error word, and the
-        time-out word of the attention + out-projection launch of the multi-launch step.  A step that gave up decoded
-        garbage: fail loudly, never report its tokens or its speed."""
+        """Host-side check (syncs) of the executor's in-launch waits: the stream engine's error word.  A step whose waits gave
+        up decoded garbage: fail loudly, never report its tokens or its speed."""
         if self.eng is not None:
             self.eng.check_error()
-        if int(self.ws.ap_sync[2].item()) != 0:
-            self.ws.ap_sync.zero_()
-            raise ParrotHipError("attention + out-projection launch: the wait for the heads timed out (workgroups of the launch "
-                                 "not resident together?); set lit_parrot_amd.ops.FUSE_ATTN_PROJ = False to use two launches")
 
 
 # The one-launch stream engine (engine.py) for the models it is built for (Llama-2 7B family, int4 g128).  Measured on

@@ -65,10 +65,6 @@ class Workspace:
         self.zero_pos = torch.zeros((1,), dtype=torch.int32, device=device)
         self.side_stream = None  # parallel-residual blocks: the MLP's first Linear runs beside the attention branch
         self.tickets = torch.zeros((c.n_head,), dtype=torch.int32, device=device)  # fused attention arrival counters
-        # attention + out-projection in one launch (ops.attn_proj_w4): the heads buffer that only that kernel touches, and its
-        # arrival counters / time-out word
-        self.heads_sync = torch.zeros((c.n_head * c.head_size,), dtype=torch.bfloat16, device=device)
-        self.ap_sync = torch.zeros((4,), dtype=torch.int32, device=device)
         self._attn_ws = {}
 
     def attn_ws(self, config: Config, nsplit: int) -> torch.Tensor:
@@ -285,11 +281,13 @@ class Block(nn.Module):
                 ws.side_stream.wait_stream(main)  # x of this block is final
                 with torch.cuda.stream(ws.side_stream):
                     self.mlp.run_up(ws, ws.x, norm=mlp_norm)  # -> ws.h
-                self.attn.run_rows_proj(ws, ws.x, pos, S, k_cache, v_cache, rope, nsplit, rope_local, self.norm_1, ws.t, ws.x)
+                self.attn.run_rows(ws, ws.x, pos, S, k_cache, v_cache, rope, nsplit, rope_local, norm=self.norm_1)
+                _linear(self.attn.proj, ws.y, ws.t, epilogue=EPI_RESIDUAL, residual=ws.x)
                 main.wait_stream(ws.side_stream)
                 self.mlp.run_down(ws, residual=ws.t, out=ws.x)
                 return
-            self.attn.run_rows_proj(ws, ws.x, pos, S, k_cache, v_cache, rope, nsplit, rope_local, self.norm_1, ws.t, ws.x)
+            self.attn.run_rows(ws, ws.x, pos, S, k_cache, v_cache, rope, nsplit, rope_local, norm=self.norm_1)  # -> ws.y
+            _linear(self.attn.proj, ws.y, ws.t, epilogue=EPI_RESIDUAL, residual=ws.x)
             self.mlp.run_rows(ws, ws.x, residual=ws.t, out=ws.x, norm=mlp_norm)
         else:
             if c.shared_attention_norm:
@@ -297,7 +295,8 @@ class Block(nn.Module):
                     "No checkpoint amongst the ones we support uses this configuration"
                     " (non-parallel residual and shared attention norm)."
                 )
-            self.attn.run_rows_proj(ws, ws.x, pos, S, k_cache, v_cache, rope, nsplit, rope_local, self.norm_1, ws.x, ws.x)  # x = x + h
+            self.attn.run_rows(ws, ws.x, pos, S, k_cache, v_cache, rope, nsplit, rope_local, norm=self.norm_1)  # -> ws.y
+            _linear(self.attn.proj, ws.y, ws.x, epilogue=EPI_RESIDUAL, residual=ws.x)  # x = x + h
             self.mlp.run_rows(ws, ws.x, residual=ws.x, out=ws.x, norm=self.norm_2)  # x = x + mlp(norm_2(x))
 
     def forward(self, x: torch.Tensor, rope: RoPECache, max_seq_length: int, mask: Optional[torch.Tensor] = None,
@@ -355,25 +354,6 @@ class CausalSelfAttention(nn.Module):
             return ops.attn_prefill(ws.q, pos, k_cache, v_cache, c.n_query_groups, c.q_per_kv, c.head_size, S, ws.y, ws.vt_scratch)
         return ops.attn_decode(ws.q, pos, k_cache, v_cache, c.n_query_groups, c.q_per_kv, c.head_size, S, nsplit,
                                ws.attn_ws(c, nsplit), ws.y)
-
-    def run_rows_proj(self, ws: Workspace, x: torch.Tensor, pos: torch.Tensor, S: int, k_cache: torch.Tensor,
-                      v_cache: torch.Tensor, rope: RoPECache, nsplit: int, rope_local: bool, norm: Optional[nn.Module],
-                      out: torch.Tensor, residual: Optional[torch.Tensor]) -> torch.Tensor:
-        """``run_rows`` followed by the output projection (+ residual) into ``out``.  A single new token whose window needs
-        no sequence split and whose projection is a GPTQ int4 Linear takes ONE launch for attention and projection
-        (``ops.attn_proj_w4``: the projection's weights stream beside the attention); everything else two."""
-        c = self.config
-        proj = self.proj
-        if (ops.FUSE_ATTN_PROJ and ws.M == 1 and not rope_local and nsplit == 1 and not LINEAR_OBSERVERS
-                and getattr(proj, "w4k_affine", False)
-                and ops.attn_proj_w4_fits(c.n_query_groups, c.q_per_kv, c.head_size, proj.out_features, proj.in_features,
-                                          proj.tile_cols, x.device)):
-            _linear(self.attn, x, ws.qkv, norm=norm)
-            return ops.attn_proj_w4(ws.qkv, rope[0], rope[1], c.rope_n_elem, pos, k_cache, v_cache, c.n_query_groups, c.q_per_kv,
-                                    c.head_size, S, ws.heads_sync, proj.packed(), proj.out_features, proj.tile_cols, out, ws.ap_sync,
-                                    bias=proj.bias, residual=residual)
-        self.run_rows(ws, x, pos, S, k_cache, v_cache, rope, nsplit, rope_local, norm=norm)  # -> ws.y
-        return _linear(proj, ws.y, out, epilogue=EPI_RESIDUAL if residual is not None else EPI_NONE, residual=residual)
 
     def forward(self, x: torch.Tensor, rope: RoPECache, max_seq_length: int, mask: Optional[torch.Tensor] = None,
                 input_pos: Optional[torch.Tensor] = None, kv_cache: Optional[KVCache] = None

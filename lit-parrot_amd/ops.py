@@ -341,48 +341,6 @@ def attn_fused_decode(qkv: torch.Tensor, cos: torch.Tensor, sin: torch.Tensor, n
     return y
 
 
-FUSE_ATTN_PROJ = True  # single-row decode: attention and the int4 out-projection in one launch (A/B: bench.py --fuse-attn-proj 0)
-
-
-def attn_proj_w4_fits(n_groups: int, q_per_kv: int, hs: int, N: int, K: int, group: int, device) -> bool:
-    """Whether parrot_attn_proj_w4 takes this shape on this device: every workgroup of the launch must be resident at once."""
-    if hs not in (64, 128) or q_per_kv > FUSED_ATTN_MAX_Q_PER_KV or K % 32 or (group > 0 and group % 32):
-        return False
-    hq = 1 if q_per_kv == 1 else (2 if q_per_kv == 2 else 4)
-    n_attn = n_groups * (-(-q_per_kv // hq))
-    # the K-slabs of the W4K plan (csrc/w4_plan.h::w4_make_plan): boundaries on group starts
-    nslices = K // 32
-    gs = (group if 0 < group <= K else K) // 32
-    unit = gs if gs <= 64 else 1
-    units = -(-nslices // unit)
-    nslabs = -(-nslices // 64)
-    while nslabs <= 16 and -(-units // nslabs) * unit > 64:
-        nslabs += 1
-    if nslabs > 16:
-        return False
-    wps = 16 // nslabs
-    cus = torch.cuda.get_device_properties(device).multi_processor_count
-    return -(-N // (wps * 8)) + n_attn <= cus
-
-
-def attn_proj_w4(qkv: torch.Tensor, cos: torch.Tensor, sin: torch.Tensor, n_elem: int, pos: torch.Tensor, k_cache: torch.Tensor,
-                 v_cache: torch.Tensor, n_groups: int, q_per_kv: int, hs: int, S: int, heads: torch.Tensor, packed: torch.Tensor,
-                 N: int, group: int, out: torch.Tensor, sync: torch.Tensor, *, bias=None, residual=None) -> torch.Tensor:
-    """Single new token: split + RoPE + KV append + attention over the whole window, then the int4 out-projection (+ bias,
-    + residual) of the heads, in one launch.  ``heads`` (n_head * hs bf16) and ``sync`` (4 zeroed int32) belong to this
-    op alone."""
-    _rows(qkv, "attn_proj_w4"), _rows(out, "attn_proj_w4")
-    if qkv.shape[0] != 1 or out.shape != (1, N) or heads.dtype != torch.bfloat16 or heads.numel() != n_groups * q_per_kv * hs:
-        raise ParrotHipError("attn_proj_w4: one row, out (1, N), heads bf16 [n_head * hs] expected")
-    if sync.dtype != torch.int32 or sync.numel() < 4 or pos.dtype != torch.int32:
-        raise ParrotHipError("attn_proj_w4: sync must be int32[4], pos int32")
-    cus = torch.cuda.get_device_properties(out.device).multi_processor_count
-    check(_hip.load().parrot_attn_proj_w4(ptr(qkv), ptr(cos), ptr(sin), n_elem, ptr(pos), n_groups, q_per_kv, hs, S, ptr(k_cache),
-                                          ptr(v_cache), ptr(heads), ptr(packed), ptr(_opt_vec(bias, N, "bias")), ptr(residual),
-                                          ptr(out), N, group, ptr(sync), cus, stream()), "parrot_attn_proj_w4")
-    return out
-
-
 # ------------------------------------------------------------------------------------------------ step glue
 def embedding(wte: torch.Tensor, tokens: torch.Tensor, pos: Optional[torch.Tensor], M: int, out: torch.Tensor) -> torch.Tensor:
     _rows(out, "embedding")

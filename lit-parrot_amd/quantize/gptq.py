@@ -73,8 +73,6 @@ class ColBlockQuantizedLinear(torch.nn.Module):
         return out
 
     # -------------------------------------------------------------------------------------- HIP path
-    w4k_affine = True  # packed() is a W4K image with {scale, zero} group words (kernels that take the image directly check this)
-
     def packed(self) -> torch.Tensor:
         """The kernel-native W4K buffer, built on first use with the repack kernel."""
         if self._packed is None:

@@ -677,67 +677,6 @@ def test_fused_decode_attention_equals_the_three_kernel_path(n_groups, q_per_kv,
         assert int(tickets.abs().sum()) == 0, "arrival tickets must be re-armed"
 
 
-@pytest.mark.parametrize("n_groups,q_per_kv,hs,n_elem,N", [(32, 1, 128, 128, 4096), (2, 2, 64, 64, 300), (40, 1, 128, 128, 5120), (8, 8, 128, 128, 8192),
-                                                         (1, 16, 64, 64, 1024), (3, 1, 128, 32, 96), (8, 4, 64, 16, 2048)])
-@pytest.mark.parametrize("group,S,use_bias,use_res", [(128, 300, False, True), (-1, 40, True, False), (64, 1024, True, True)])
-def test_attention_and_out_projection_in_one_launch(n_groups, q_per_kv, hs, n_elem, N, group, S, use_bias, use_res):
-    """parrot_attn_proj_w4 == parrot_attn_fused_decode (one split) + parrot_w4_gemv with the residual epilogue: the caches bit for
-    bit; the projection against float64 on the two-launch path's heads (<= 1 bf16 ulp: the fused kernel sums a row's lanes in
-    a different tree) and almost always bit-identical to the two-launch output.  Steps around a ring wrap; the arrival
-    counters are re-armed after every launch and the time-out word stays clear."""
-    g = gen(31)
-    n_head, width, K = n_groups * q_per_kv, n_groups * (q_per_kv + 2) * hs, n_groups * q_per_kv * hs
-    qw, s, z, tc, wd = make_w4(N, K, group, 32)
-    bias = (torch.randn(N, generator=g) * 0.1).to(BF) if use_bias else None
-    lin = w4_module(qw, s, z, N, K, group, bias)
-    assert ops.attn_proj_w4_fits(n_groups, q_per_kv, hs, N, K, lin.tile_cols, DEV)
-    cos, sin = (t.to(DEV) for t in om.rope_tables(2048, n_elem, BF, math_dtype=BF))
-    kc1 = torch.zeros((n_groups, S, hs), dtype=BF, device=DEV); vc1 = torch.zeros_like(kc1)
-    kc2 = torch.zeros_like(kc1); vc2 = torch.zeros_like(kc1)
-    y1 = torch.empty((1, K), dtype=BF, device=DEV)
-    heads = torch.zeros((K,), dtype=BF, device=DEV)
-    sync = torch.zeros((4,), dtype=torch.int32, device=DEV)
-    ws1 = ops.attn_workspace(1, n_head, hs, 1, DEV)
-    tickets = torch.zeros((n_head,), dtype=torch.int32, device=DEV)
-    o1 = torch.empty((1, N), dtype=BF, device=DEV)
-    identical = total = 0
-    for pos in list(range(0, 6)) + list(range(S - 3, S + 5)):
-        qkv = torch.randn(1, width, generator=g).to(BF).to(DEV)
-        res = (torch.randn(1, N, generator=g)).to(BF).to(DEV) if use_res else None
-        pos_d = torch.tensor([pos], dtype=torch.int32, device=DEV)
-        if pos == S - 3:
-            fill = torch.randn((n_groups, S, hs), generator=g).to(BF).to(DEV)
-            for c_ in (kc1, vc1, kc2, vc2):
-                c_.copy_(fill)
-        ops.attn_fused_decode(qkv, cos, sin, n_elem, pos_d, kc1, vc1, n_groups, q_per_kv, hs, S, 1, ws1, tickets, y1)
-        ops.w4_linear(lin.packed(), N, K, lin.tile_cols, y1, o1, bias=lin.bias, epilogue=EPI_RESIDUAL if use_res else EPI_NONE, residual=res)
-        o2 = res.clone() if use_res else torch.empty((1, N), dtype=BF, device=DEV)  # in place, as the sequential block does
-        ops.attn_proj_w4(qkv, cos, sin, n_elem, pos_d, kc2, vc2, n_groups, q_per_kv, hs, S, heads, lin.packed(), N, lin.tile_cols, o2, sync,
-                         bias=lin.bias, residual=o2 if use_res else None)
-        assert torch.equal(kc1, kc2) and torch.equal(vc1, vc2), f"cache differs at pos {pos}"
-        assert torch.equal(heads.view(1, -1), y1), f"the heads differ from the two-launch path at pos {pos}"
-        want = expected_epilogue(y1.cpu().double() @ wd.T, None, bias, res.cpu() if use_res else None, EPI_RESIDUAL if use_res else EPI_NONE)
-        assert_bf16_close(o2, want, ulps=1, atol=2e-3, what=f"attn_proj_w4 pos {pos}")
-        identical += int((o1 == o2).sum()); total += o1.numel()
-        assert sync.tolist() == [0, 0, 0, 0], f"arrival counters / time-out word after the launch: {sync.tolist()}"
-    assert identical / total > 0.97, f"only {identical / total:.3f} of the outputs equal the two-launch path bit for bit"
-
-
-def test_attention_and_out_projection_refuse_what_does_not_fit():
-    """More workgroups than are resident at once -> PARROT_EUNSUPPORTED (never a launch that could wait for itself)."""
-    qw, s, z, tc, wd = make_w4(4096, 4096, 128, 5)
-    lin = w4_module(qw, s, z, 4096, 4096, 128)
-    cos, sin = (t.to(DEV) for t in om.rope_tables(64, 128, BF, math_dtype=BF))
-    kc = torch.zeros((32, 16, 128), dtype=BF, device=DEV)
-    args = (torch.zeros(1, 3 * 4096, dtype=BF, device=DEV).data_ptr(), cos.data_ptr(), sin.data_ptr(), 128, torch.zeros(1, dtype=torch.int32, device=DEV).data_ptr(),
-            32, 1, 128, 16, kc.data_ptr(), torch.zeros_like(kc).data_ptr(), torch.zeros(4096, dtype=BF, device=DEV).data_ptr(), lin.packed().data_ptr(),
-            None, None, torch.zeros(1, 4096, dtype=BF, device=DEV).data_ptr(), 4096, 128, torch.zeros(4, dtype=torch.int32, device=DEV).data_ptr())
-    from lit_parrot_amd import _hip
-    lib = _hip.load()
-    assert lib.parrot_attn_proj_w4(*args, 64, 0) == -3 and "resident" in _hip.last_error()
-    assert lib.parrot_attn_proj_w4(*args[:7], 32, *args[8:], 256, 0) == -3  # head size 32 is not built
-
-
 @pytest.mark.parametrize("n_groups,q_per_kv,hs", [(4, 1, 128), (2, 4, 64), (1, 3, 32), (8, 16, 64)])
 @pytest.mark.parametrize("M,S,pos0", [(32, 32, 0), (100, 128, 0), (257, 300, 0), (70, 200, 37), (512, 512, 0)])
 def test_prefill_attention_on_the_matrix_cores_equals_the_row_by_row_path(n_groups, q_per_kv, hs, M, S, pos0):
