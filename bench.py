@@ -352,6 +352,7 @@ def main() -> None:
     ap.add_argument("--devices", default="", help="comma list of HIP_VISIBLE_DEVICES values for the replicas spawned by --gpus N (default 0..N-1)")
     ap.add_argument("--attn-split-keys", type=int, default=0, help="A/B: window slots per sequence split of the decode attention (default: the library's)")
     ap.add_argument("--engine", type=int, default=-1, help="1 / 0: force the one-launch stream engine on / off (default: the library's choice)")
+    ap.add_argument("--no-sampled", action="store_true", help="skip the sampled-decode leg (generate's default call: temperature 0.8, top_k 200)")
     ap.add_argument("--watchdog", type=float, default=300.0, help="seconds without a phase change before the run reports where it is stuck and exits 3 (0: off)")
     args = ap.parse_args()
 
@@ -449,6 +450,30 @@ def main() -> None:
             sess._step()
         stats = _hip.prof_end()
         sess.check_error()
+
+        # the reference's DEFAULT call samples (generate/base.py:165-166: temperature 0.8, top_k 200): the same model and
+        # prompt with the sampling step inside the captured graph (torch's noise draw + parrot_topk_sample)
+        sampled = None
+        if not args.no_sampled:
+            wd.phase("sampled decode (temperature 0.8, top_k 200)")
+            n_s = min(args.steps, 128)
+            s2 = _session(model, total, total, greedy=False, sampler=(0.8, 200))
+            torch.manual_seed(1234)
+            lg = s2.prefill(prompt.to(device))
+            s2.sample(lg)
+            s2.capture()
+            for _ in range(8):
+                s2.step()
+            torch.cuda.synchronize(device)
+            t1 = time.perf_counter()
+            for _ in range(n_s):
+                s2.step()
+            torch.cuda.synchronize(device)
+            el_s = time.perf_counter() - t1
+            s2.check_error()
+            assert int(s2.pos.item()) == T + 8 + n_s, int(s2.pos.item())
+            sampled = {"value": n_s / el_s, "steps": n_s, "ms_per_step": el_s / n_s * 1e3, "temperature": 0.8, "top_k": 200,
+                       "engine": s2.eng is not None}
     wd.phase("summary")
 
     ms_per_step = elapsed_max / args.steps * 1e3
@@ -506,6 +531,9 @@ def main() -> None:
                              "frac": prefill_flops / t_pre / 1e12 / MFMA_BF16_PEAK_TFLOPS, "linear_flops": prefill_flops},
         "build_s": t_build,
         "engine": sess.eng is not None,
+        # generate()'s default call (temperature 0.8, top_k 200) with the sampling step inside the graph; greedy = `value`
+        "sampled_tokens_per_s": None if sampled is None else sampled["value"],
+        "sampled": sampled,
     }
     if replica is not None:  # the parent aggregates: it needs this replica's own clock
         result.update(elapsed_s=elapsed, device=os.environ.get("HIP_VISIBLE_DEVICES", "?"), cpu_baseline=None)

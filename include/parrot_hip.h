@@ -226,6 +226,15 @@ int parrot_gptq_block(void* W, int ldw, int rows, int col0, int ncols, const voi
 int parrot_stop_check(const int64_t* tokens, const int32_t* pos, const int32_t* first_gen, const int64_t* stop_flat,
                       const int32_t* stop_off, int n_stop, int longest, int32_t* flag, void* stream);
 int parrot_argmax_advance(const void* logits, int V, int64_t* tokens, int32_t* pos, void* stream);
+/* The sampling step of generate() for top_k != 1 (generate/base.py:136-153; chat/base.py:60-72) in one launch, with the arithmetic
+ * of the torch device ops the reference runs there: logits / temperature (bf16), keep the values >= the top_k-th largest
+ * (top_k <= 0: all), softmax (fp32 inside, bf16 out), then multinomial's draw = argmax(probs / q) with q the bf16
+ * Exponential(1) noise that the CALLER draws with torch (`empty_like(probs).exponential_(1)`: exactly the call
+ * torch.multinomial makes, so the same generator state gives the same token; it can be captured in a hipGraph), lowest index on
+ * ties; tokens[*pos + 1] = idx, *pos += 1.  logits, noise_exp1: bf16 [V]; probs_out: bf16 [V] or NULL (the probabilities, for
+ * tests).  torch.multinomial's validity checks (two host syncs per token) are not reproduced.                                 */
+int parrot_topk_sample(const void* logits, int V, float temperature, int top_k, const void* noise_exp1, void* probs_out,
+                       int64_t* tokens, int32_t* pos, void* stream);
 
 /* ---- stream engine: ONE launch per decode token ------------------------------------------------------------
  * The whole token (generate/base.py:131-153 for one iteration: embedding, every Block of lit_gpt/model.py:158-180,

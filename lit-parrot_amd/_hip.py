@@ -103,6 +103,7 @@ SIGNATURES = {
     "parrot_gptq_block": (_i, [_vp, _i, _i, _i, _i, _vp, _i, _vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _vp]),
     "parrot_stop_check": (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _vp, _vp]),
     "parrot_argmax_advance": (_i, [_vp, _i, _vp, _vp, _vp]),
+    "parrot_topk_sample": (_i, [_vp, _i, _f, _i, _vp, _vp, _vp, _vp, _vp]),
 }
 
 _lib: Optional[C.CDLL] = None

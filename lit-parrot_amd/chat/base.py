@@ -55,10 +55,11 @@ class _StopState:
 
 
 class ChatSession(DecodeSession):
-    """DecodeSession whose greedy step also runs the device-side stop check (captured in the same graph)."""
+    """DecodeSession whose step - greedy, or sampling inside the graph (generate/base.py) - also runs the device-side stop
+    check (captured in the same graph)."""
 
-    def __init__(self, model: GPT, max_seq_length: int, max_tokens: int, greedy: bool) -> None:
-        super().__init__(model, max_seq_length, max_tokens, greedy)  # the library's choice of executor (generate/base.py)
+    def __init__(self, model: GPT, max_seq_length: int, max_tokens: int, greedy: bool, sampler=None) -> None:
+        super().__init__(model, max_seq_length, max_tokens, greedy, sampler=sampler)  # the library's choice of executor (generate/base.py)
         self.stop = _StopState(self.device)
         self.n_stop_captured = None
 
@@ -68,20 +69,20 @@ class ChatSession(DecodeSession):
 
     def _step(self) -> None:
         super()._step()
-        if self.greedy:
-            self.check()
+        self.check()
 
 
-def _session(model: GPT, max_seq_length: int, max_tokens: int, greedy: bool, n_stop: int, longest: int) -> ChatSession:
+def _session(model: GPT, max_seq_length: int, max_tokens: int, greedy: bool, n_stop: int, longest: int, sampler=None) -> ChatSession:
     cache = model.__dict__.setdefault("_chat_sessions", {})
+    sampler = None if greedy else sampler
     # the number of sequences and the longest one are launch arguments of the captured stop check
-    key = (max_seq_length, greedy, n_stop, longest)
+    key = (max_seq_length, greedy, n_stop, longest, sampler)
     sess = cache.get(key)
     stale = (sess is None or sess.tokens.numel() < max_tokens + 1 or not model.kv_caches
              or model.kv_caches[0][0].data_ptr() != sess.caches[0][0].data_ptr())
     if stale:
         cache.pop(key, None)
-        sess = ChatSession(model, max_seq_length, max_tokens, greedy)
+        sess = ChatSession(model, max_seq_length, max_tokens, greedy, sampler)
         cache[key] = sess
     return sess
 
@@ -113,27 +114,15 @@ def generate(
     greedy = top_k == 1 and temperature > 0
     n_stop = len(stop_tokens)
     L = max((len(s) for s in stop_tokens), default=1)
-    sess = _session(model, max_seq_length, max_returned_tokens, greedy, n_stop, L)
+    sess = _session(model, max_seq_length, max_returned_tokens, greedy, n_stop, L, (float(temperature), top_k))
     sess.stop.arm(stop_tokens, T)
     dtype = idx.dtype
     n_new = max_returned_tokens - T
     logits = sess.prefill(idx.to(device=sess.device, dtype=torch.int64))
     sess.capture()
 
-    def sample(lg: torch.Tensor) -> None:  # writes tokens[pos+1], advances pos, then runs the stop check
-        if greedy:
-            ops.argmax_advance(lg, sess.tokens, sess.pos)
-        else:
-            lg = lg.view(-1) / temperature
-            if top_k is not None:
-                v, _ = torch.topk(lg, min(top_k, lg.size(-1)))
-                lg = torch.where(lg < v[[-1]], -float("Inf"), lg)
-            nxt = torch.multinomial(torch.nn.functional.softmax(lg, dim=-1), num_samples=1)
-            sess.tokens.index_copy_(0, (sess.pos + 1).to(torch.int64), nxt)
-            sess.pos.add_(1)
-        sess.check()
-
-    sample(logits)  # generated token 0 (greedy steps inside the graph sample and check by themselves)
+    sess.sample(logits)  # generated token 0: arg-max, or the reference's sampling step (later steps sample inside the graph)
+    sess.check()
     done = 1        # generated tokens present in sess.tokens[T : T + done]
     emitted = 0     # steps t whose yield decision has been taken
     while True:
@@ -152,9 +141,7 @@ def generate(
         emitted = upto
         if done >= n_new:
             return
-        steps = min(CHUNK if greedy else 1, n_new - done)
+        steps = min(CHUNK, n_new - done)
         for _ in range(steps):
-            lg = sess.step()
-            if not greedy:
-                sample(lg)
+            sess.step()  # model + sampling + stop check: one graph replay
         done += steps

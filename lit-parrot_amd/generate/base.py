@@ -9,10 +9,13 @@ temperature, optional top-k crop, softmax, multinomial, out-of-place ``index_cop
 
 and one decode step — embedding of ``tokens[pos]``, every block, final norm, lm_head and, for greedy decoding, the
 arg-max that writes ``tokens[pos+1]`` and advances ``pos`` — is a fixed launch sequence captured ONCE per
-(model, max_seq_length) in a hipGraph and replayed per token.  Greedy decoding (``top_k == 1``, which is how the
-reference spells it: there is no argmax branch) never touches the host inside the loop unless ``eos_id`` is set.
-With ``top_k != 1`` the graph stops at the logits and the reference's own sampling ops (topk / where / softmax /
-multinomial, :139-144) run as torch ops on the device, so the same torch seed draws the same tokens.
+(model, max_seq_length, sampling parameters) in a hipGraph and replayed per token.  Greedy decoding (``top_k == 1``, which
+is how the reference spells it: there is no argmax branch) never touches the host inside the loop unless ``eos_id`` is set.
+With ``top_k != 1`` (the reference's default call: temperature 0.8, top_k 200) the sampling step is inside the graph too:
+torch draws the Exponential(1) noise that ``torch.multinomial`` draws internally (``noise.exponential_(1)``, graph-safe
+Philox: the same generator consumption) and ``parrot_topk_sample`` does the rest - temperature, top-k crop, softmax,
+arg-max of probs / noise - with the arithmetic of the torch device ops the reference runs (:139-144), so the same torch seed
+draws the same tokens as those ops do on this device (tests/test_model_gpu.py::test_sampling_in_the_graph_draws_the_tokens_of_the_torch_ops).
 
 The prompt is prefilled in one multi-row pass (same kernels, M = T rows) that computes only the last row of lm_head
 (the reference computes all T rows and discards T-1 of them, :135-136).
@@ -30,8 +33,11 @@ class DecodeSession:
     """Static buffers + captured graph of the single-token step for one (model, max_seq_length, greedy) choice."""
 
     def __init__(self, model: GPT, max_seq_length: int, max_tokens: int, greedy: bool, use_graph: bool = True,
-                 engine: Optional[bool] = None) -> None:
+                 engine: Optional[bool] = None, sampler: Optional[Tuple[float, Optional[int]]] = None) -> None:
         self.model, self.S, self.greedy = model, max_seq_length, greedy
+        # (temperature, top_k) of the in-graph sampling step when not greedy; None: the step ends at the logits
+        self.sampler = None if greedy else sampler
+        self.noise: Optional[torch.Tensor] = None
         dev = model.transformer.wte.weight.device
         if dev.type != "cuda":
             raise ParrotHipError("generate() runs on the HIP device only: move the model to cuda (no CPU fallback)")
@@ -61,11 +67,27 @@ class DecodeSession:
     # one decode step = the launch sequence that gets captured
     def _step(self) -> None:
         if self.eng is not None:
-            self.eng.step()  # embedding .. lm_head (.. arg-max + advance when greedy) in one launch
-            return
-        logits = self.model.run_rows(self.ws, self.tokens, self.pos, self.pos, self.S, self.caches, self.model.rope_cache)
+            logits = self.eng.step()  # embedding .. lm_head (.. arg-max + advance when greedy) in one launch
+        else:
+            logits = self.model.run_rows(self.ws, self.tokens, self.pos, self.pos, self.S, self.caches, self.model.rope_cache)
+            if self.greedy:
+                ops.argmax_advance(logits, self.tokens, self.pos)
+        if self.sampler is not None:
+            self.sample(logits)
+
+    def sample(self, logits: torch.Tensor) -> None:
+        """``tokens[pos + 1]`` = the next token drawn from ``logits`` (the row at ``pos``), ``pos += 1``: arg-max when greedy,
+        else the reference's temperature / top-k / softmax / multinomial step (generate/base.py:136-153) as one torch draw of
+        the noise + one launch (ops.topk_sample)."""
         if self.greedy:
             ops.argmax_advance(logits, self.tokens, self.pos)
+            return
+        if self.sampler is None:
+            raise ParrotHipError("this session was built without sampling parameters")
+        if self.noise is None:
+            self.noise = torch.empty((logits.numel(),), dtype=torch.bfloat16, device=self.device)
+        self.noise.exponential_(1)  # what torch.multinomial draws internally: same generator consumption
+        ops.topk_sample(logits.view(-1), self.sampler[0], self.sampler[1], self.noise, self.tokens, self.pos)
 
     def prefill(self, prompt: torch.Tensor) -> torch.Tensor:
         """Run the T prompt rows, leave ``pos`` = T-1 and return the logits of the last prompt token."""
@@ -126,9 +148,11 @@ ENGINE_DEFAULT = "auto"
 ENGINE_AUTO_MIN_WINDOW = 1024
 
 
-def _session(model: GPT, max_seq_length: int, max_tokens: int, greedy: bool) -> DecodeSession:
+def _session(model: GPT, max_seq_length: int, max_tokens: int, greedy: bool,
+             sampler: Optional[Tuple[float, Optional[int]]] = None) -> DecodeSession:
     cache: Dict[Tuple, DecodeSession] = model.__dict__.setdefault("_decode_sessions", {})
-    key = (max_seq_length, greedy)
+    sampler = None if greedy else sampler
+    key = (max_seq_length, greedy, sampler)
     sess = cache.get(key)
     stale = (
         sess is None
@@ -138,7 +162,7 @@ def _session(model: GPT, max_seq_length: int, max_tokens: int, greedy: bool) -> 
     )
     if stale:
         cache.pop(key, None)
-        sess = DecodeSession(model, max_seq_length, max_tokens, greedy)
+        sess = DecodeSession(model, max_seq_length, max_tokens, greedy, sampler=sampler)
         cache[key] = sess
     return sess
 
@@ -170,25 +194,16 @@ def generate(
     assert max_seq_length >= T, f"Cannot forward sequence of length {T}, max seq length is only {max_seq_length}"
     dtype = idx.dtype
     greedy = top_k == 1 and temperature > 0
-    sess = _session(model, max_seq_length, max_returned_tokens, greedy)
+    sess = _session(model, max_seq_length, max_returned_tokens, greedy, (float(temperature), top_k))
     logits = sess.prefill(idx.to(device=sess.device, dtype=torch.int64))
     sess.capture()
 
     n_new = max_returned_tokens - T
     for i in range(n_new):
-        # `logits` belong to the row at `pos` = T-1+i; sample tokens[T+i] from them and advance `pos`.
-        if greedy:
-            if i == 0:
-                ops.argmax_advance(logits, sess.tokens, sess.pos)  # later steps sample inside the captured graph
-        else:
-            lg = logits.view(-1) / temperature
-            if top_k is not None:
-                v, _ = torch.topk(lg, min(top_k, lg.size(-1)))
-                lg = torch.where(lg < v[[-1]], -float("Inf"), lg)
-            probs = torch.nn.functional.softmax(lg, dim=-1)
-            idx_next = torch.multinomial(probs, num_samples=1)
-            sess.tokens.index_copy_(0, (sess.pos + 1).to(torch.int64), idx_next)
-            sess.pos.add_(1)
+        # `logits` belong to the row at `pos` = T-1+i; sample tokens[T+i] from them and advance `pos`: the first token here,
+        # the later ones inside the captured step (arg-max, or the noise draw + parrot_topk_sample)
+        if i == 0:
+            sess.sample(logits)
         if eos_id is not None and int(sess.tokens[T + i]) == eos_id:  # host sync, as in the reference (:156-157)
             # the reference returns idx[:input_pos], which stops BEFORE the eos token despite its comment
             break

@@ -358,6 +358,23 @@ def argmax_advance(logits: torch.Tensor, tokens: torch.Tensor, pos: torch.Tensor
           "parrot_argmax_advance")
 
 
+def topk_sample(logits: torch.Tensor, temperature: float, top_k: Optional[int], noise: torch.Tensor, tokens: torch.Tensor,
+                pos: torch.Tensor, probs_out: Optional[torch.Tensor] = None) -> None:
+    """The reference's sampling step (generate/base.py:136-153) in one launch: ``tokens[pos + 1]`` = the token that
+    ``torch.multinomial(softmax(topk-cropped(logits / temperature)), 1)`` draws when its internal noise is ``noise`` -
+    a bf16 (V,) buffer the caller fills with ``noise.exponential_(1)`` right before (the call torch.multinomial makes itself,
+    so a torch seed gives the tokens the reference's ops give on this device); ``pos += 1``."""
+    V = logits.numel()
+    if logits.dtype != torch.bfloat16 or noise.dtype != torch.bfloat16 or noise.numel() != V or tokens.dtype != torch.int64 or pos.dtype != torch.int32:
+        raise ParrotHipError("topk_sample: logits / noise bf16 (V,), tokens int64, pos int32 expected")
+    if probs_out is not None and (probs_out.dtype != torch.bfloat16 or probs_out.numel() != V):
+        raise ParrotHipError("topk_sample: probs_out must be bf16 (V,)")
+    if not temperature > 0:
+        raise ParrotHipError(f"topk_sample: temperature must be positive (got {temperature})")
+    check(_hip.load().parrot_topk_sample(ptr(logits), V, float(temperature), int(top_k) if top_k is not None else 0, ptr(noise),
+                                         ptr(probs_out), ptr(tokens), ptr(pos), stream()), "parrot_topk_sample")
+
+
 def stop_check(tokens: torch.Tensor, pos: torch.Tensor, first_gen: torch.Tensor, stop_flat: torch.Tensor,
                stop_off: torch.Tensor, n_stop: int, longest: int, flag: torch.Tensor) -> None:
     """Latch in ``flag`` (int32[2]) the first stop sequence that the generated tokens end with (chat loop)."""

@@ -755,6 +755,54 @@ def test_embedding_and_argmax_advance():
         tok_d[5:7] = 0
 
 
+@pytest.mark.parametrize("V", [512, 1003, 32000, 50688, 65024])
+@pytest.mark.parametrize("top_k,temperature", [(200, 0.8), (5, 0.8), (None, 1.0), (1, 0.7), (100000, 1.3)])
+def test_topk_sample_draws_what_the_torch_ops_draw(V, top_k, temperature):
+    """parrot_topk_sample against the device ops the reference's sampling step runs (generate/base.py:136-144): the
+    probabilities bit for bit, and with the same torch seed the token torch.multinomial draws - the noise handed to the kernel
+    is the very draw multinomial makes internally (empty_like(probs).exponential_(1))."""
+    g = gen(40)
+    tokens = torch.zeros((64,), dtype=torch.int64, device=DEV)
+    pos = torch.zeros((1,), dtype=torch.int32, device=DEV)
+    noise = torch.empty((V,), dtype=BF, device=DEV)
+    probs = torch.empty((V,), dtype=BF, device=DEV)
+    for trial in range(12):
+        lg = (torch.randn(V, generator=g) * (3.0 if trial % 3 else 0.5)).to(BF)
+        if trial == 3:
+            lg[: V // 2] = lg[V // 2: V // 2 * 2]  # many exact ties, also across the k-th value
+        if trial == 4:
+            lg[::7] = float("-inf")
+        if trial == 5:
+            lg[:] = 0.25  # one value: everything is kept whatever k is
+        lg = lg.to(DEV)
+        t = lg / temperature
+        if top_k is not None:
+            v, _ = torch.topk(t, min(top_k, V))
+            t = torch.where(t < v[[-1]], -float("Inf"), t)
+        want_p = torch.nn.functional.softmax(t, dim=-1)
+        torch.manual_seed(100 + trial)
+        want = int(torch.multinomial(want_p, num_samples=1))
+        torch.manual_seed(100 + trial)
+        noise.exponential_(1)
+        pos.fill_(trial)
+        ops.topk_sample(lg, temperature, top_k, noise, tokens, pos, probs_out=probs)
+        diff = int((probs != want_p).sum())
+        assert diff == 0, f"trial {trial}: {diff} of {V} probabilities differ from torch's softmax bits"
+        assert int(pos) == trial + 1 and int(tokens[trial + 1]) == want, f"trial {trial}: drew {int(tokens[trial + 1])}, torch.multinomial {want}"
+
+
+def test_topk_sample_bad_arguments():
+    tokens = torch.zeros((4,), dtype=torch.int64, device=DEV)
+    pos = torch.zeros((1,), dtype=torch.int32, device=DEV)
+    lg = torch.zeros((64,), dtype=BF, device=DEV)
+    with pytest.raises(ParrotHipError):
+        ops.topk_sample(lg, 0.0, 5, torch.ones_like(lg), tokens, pos)
+    with pytest.raises(ParrotHipError):
+        ops.topk_sample(lg, 1.0, 5, torch.ones((32,), dtype=BF, device=DEV), tokens, pos)
+    with pytest.raises(ParrotHipError):
+        ops.topk_sample(lg.float(), 1.0, 5, torch.ones_like(lg), tokens, pos)
+
+
 def test_profiling_sink_reports_kernels():
     from lit_parrot_amd import _hip
 

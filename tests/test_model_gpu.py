@@ -361,6 +361,66 @@ def test_generate_eos_and_sampling_paths():
             logits = oracle(a[6 + i].view(1, 1), 20, pos)[0, -1].float()
 
 
+@pytest.mark.parametrize("name,top_k,temperature", [("tiny-llama", 5, 0.8), ("tiny-llama", 200, 0.8), ("tiny-neox", None, 1.0), ("tiny-falcon-7b", 3, 1.5)])
+def test_sampling_in_the_graph_draws_the_tokens_of_the_torch_ops(name, top_k, temperature):
+    """generate(top_k != 1): the sampling step is captured in the hipGraph (torch's exponential_ draw + parrot_topk_sample).
+    With the same torch seed it must return the tokens of the reference's own loop of device ops - logits / temperature,
+    topk, where, softmax, torch.multinomial (generate/base.py:131-153) - run eagerly here on the same model, on both
+    executors; and a second call repeats it."""
+    from lit_parrot_amd.generate import base as gb
+
+    cfg = Config.from_name(name)
+    sd = {k: v.to(BF) for k, v in synthetic_state_dict(cfg, MODEL_SEED, perturb=True).items()}
+    model = hip_model(cfg, sd)
+    prompt = synthetic_prompt(cfg, 6, 2).to(DEV)
+    n_total = 40
+
+    def reference_loop(seed):  # the reference's sampling ops, op for op, on the logits of the (eager, multi-launch) decode step
+        torch.manual_seed(seed)
+        model.reset_cache()
+        with torch.no_grad():
+            sess = gb.DecodeSession(model, n_total, n_total, greedy=False, use_graph=False, engine=False)  # the step ends at the logits
+            logits = sess.prefill(prompt.to(torch.int64))
+            for i in range(n_total - 6):
+                lg = logits.view(-1) / temperature
+                if top_k is not None:
+                    v, _ = torch.topk(lg, min(top_k, lg.size(-1)))
+                    lg = torch.where(lg < v[[-1]], -float("Inf"), lg)
+                probs = torch.nn.functional.softmax(lg, dim=-1)
+                idx_next = torch.multinomial(probs, num_samples=1)
+                sess.tokens.index_copy_(0, (sess.pos + 1).to(torch.int64), idx_next)
+                sess.pos.add_(1)
+                if i + 1 < n_total - 6:
+                    logits = sess.step()
+            out = sess.tokens[:n_total].to(prompt.dtype).cpu()
+        model.reset_cache()
+        return out
+
+    want = reference_loop(7)
+    for engine in (False, True):
+        gb.ENGINE_DEFAULT = engine
+        try:
+            model.reset_cache()
+            model.__dict__.pop("_decode_sessions", None)
+            torch.manual_seed(7)
+            a = L.generate(model, prompt, n_total, n_total, temperature=temperature, top_k=top_k).cpu()
+            sess = next(iter(model._decode_sessions.values()))
+            assert sess.graph is not None and (sess.eng is not None) == engine
+            model.reset_cache()
+            torch.manual_seed(7)
+            b = L.generate(model, prompt, n_total, n_total, temperature=temperature, top_k=top_k).cpu()
+        finally:
+            gb.ENGINE_DEFAULT = "auto"
+        assert torch.equal(a, b), "same seed, different tokens"
+        if not engine:  # (the engine's logits differ from the multi-launch step's in the last bits: a different model of the same draws)
+            assert torch.equal(a, want), f"tokens differ from the torch-op loop: {a.tolist()} vs {want.tolist()}"
+        assert a.shape == (n_total,) and torch.equal(a[:6], prompt.cpu())
+    torch.manual_seed(8)
+    model.reset_cache()
+    c = L.generate(model, prompt, n_total, n_total, temperature=temperature, top_k=top_k).cpu()
+    assert not torch.equal(c, want) or top_k == 1  # another seed, other draws
+
+
 def test_block_and_attention_standalone_calls():
     """Block.forward / CausalSelfAttention.forward keep the reference's call signature (used by its tests and by
     quantize/gptq.py:501-503)."""
