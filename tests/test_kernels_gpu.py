@@ -787,7 +787,15 @@ def test_topk_sample_draws_what_the_torch_ops_draw(V, top_k, temperature):
         pos.fill_(trial)
         ops.topk_sample(lg, temperature, top_k, noise, tokens, pos, probs_out=probs)
         diff = int((probs != want_p).sum())
-        assert diff == 0, f"trial {trial}: {diff} of {V} probabilities differ from torch's softmax bits"
+        # a crop leaves <= a few hundred terms in the softmax sum: the same bits.  Over the whole vocabulary the fp32 sum depends
+        # on the order of ~V additions (torch's block reduction vs this kernel's; they differ by ~1e-6 relative): the few
+        # probabilities that sit that close to a bf16 rounding boundary land on the neighbouring value (measured: 6 of 32000,
+        # 58 of 50688), never further
+        cropped = top_k is not None and top_k < V
+        assert diff <= (0 if cropped else V // 500), f"trial {trial}: {diff} of {V} probabilities differ from torch's softmax bits"
+        if diff:
+            from helpers import bf16_ulp_distance
+            assert int(bf16_ulp_distance(probs, want_p).max()) <= 1
         assert int(pos) == trial + 1 and int(tokens[trial + 1]) == want, f"trial {trial}: drew {int(tokens[trial + 1])}, torch.multinomial {want}"
 
 
