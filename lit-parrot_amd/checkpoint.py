@@ -147,6 +147,9 @@ def stream_load(model: torch.nn.Module, state_dict: Dict[str, torch.Tensor]) -> 
     from .quantize.gptq import ColBlockQuantizedLinear, pack_nibbles, rtn_quantize
 
     modules = dict(model.named_modules())
+    for m in modules.values():  # (an int4 Linear whose reference-layout buffers a decode session released: resident again)
+        if isinstance(m, ColBlockQuantizedLinear):
+            m.restore_reference()
     own = dict(model.state_dict(keep_vars=True))
     unused = []
     for key, value in state_dict.items():
@@ -160,6 +163,7 @@ def stream_load(model: torch.nn.Module, state_dict: Dict[str, torch.Tensor]) -> 
             mod.zeros.copy_(z)
             mod.quant_weight.copy_(pack_nibbles(q))
             mod._packed = None
+            mod.image_epoch += 1
             del w, q, s, z
         elif isinstance(mod, (InferenceLinear8bitLt, Linear4bit)) and leaf == "weight" and value.is_floating_point():
             mod._quantize_weight(value.to(mod.weight.device))

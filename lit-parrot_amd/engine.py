@@ -32,26 +32,27 @@ def e4_image(lin: ColBlockQuantizedLinear, partner: Optional[ColBlockQuantizedLi
     nbytes = lib.parrot_e4_bytes(N, k1 - k0, int(partner is not None))
     if nbytes < 0:
         raise ParrotHipError(f"parrot_e4_bytes failed ({nbytes}): {_hip.last_error()}")
-    out = torch.empty((nbytes,), dtype=torch.uint8, device=lin.quant_weight.device)
     keep = []
 
     def bufs(m):
-        if m.quant_weight.stride() != (1, m.out_features):
+        qw, scales, zeros = m.reference_buffers()  # (rebuilt from the W4K image when the module has released its own)
+        if qw.stride() != (1, m.out_features):
             raise ParrotHipError("ColBlockQuantizedLinear.quant_weight lost its column-major layout")
         g0, g1 = k0 // 128, -(-k1 // 128)
         if m.tile_cols == 128:
-            s, z = m.scales[:, g0:g1], m.zeros[:, g0:g1]
+            s, z = scales[:, g0:g1], zeros[:, g0:g1]
         elif m.tile_cols >= m.in_features:  # one scale per row (the reference's "gptq.int4"): the same for every group of 128
-            s, z = m.scales[:, :1].expand(-1, g1 - g0), m.zeros[:, :1].expand(-1, g1 - g0)
+            s, z = scales[:, :1].expand(-1, g1 - g0), zeros[:, :1].expand(-1, g1 - g0)
         else:
             raise ParrotHipError(f"e4_image: int4 group size {m.tile_cols} (128, or one group per row)")
         s, z = s.to(torch.bfloat16).contiguous(), z.to(torch.bfloat16).contiguous()
-        q = m.quant_weight[:, k0 // 2:k1 // 2]  # storage rows k0/2 .. k1/2 of the (K/2, N) array: contiguous
+        q = qw[:, k0 // 2:k1 // 2]  # storage rows k0/2 .. k1/2 of the (K/2, N) array: contiguous
         keep.extend((s, z, q))
         return ptr(q), ptr(s), ptr(z)
 
     q1, s1, z1 = bufs(lin)
     q2, s2, z2 = bufs(partner) if partner is not None else (None, None, None)
+    out = torch.empty((nbytes,), dtype=torch.uint8, device=keep[0].device)
     check(lib.parrot_e4_repack(q1, s1, z1, q2, s2, z2, N, k1 - k0, ptr(out), _hip.stream()), "parrot_e4_repack")
     return out
 
@@ -248,9 +249,14 @@ class StreamEngine:
                 off += n
             raise KeyError(name)
 
-        self.images = []  # keeps the E4 / E16 images alive
+        self.images = []  # keeps the E4 / E16 / E8 images of this engine's ops alive
         ops_list: List[EngOp] = []
 
+        # The kernel-layout images belong to the MODEL, not to the session: generate()'s caller resets the KV caches between
+        # prompts (model.reset_cache(), generate/base.py:250 of the reference), the session and its engine are rebuilt, and a
+        # rebuilt engine must not repack (and, for a moment, hold a second copy of) every weight.  Keyed by the Linear, its
+        # partner, the K-chunk and the state of the weights the image was built from.
+        model_images = model.__dict__.setdefault("_engine_images", {})
         images = {}
         self.kmax = 0
         chunks = self._down_chunks(c, wfmt)
@@ -285,14 +291,23 @@ class StreamEngine:
                 op.bias = ptr(lin.bias.data)
             img = images.get((id(lin), k0, k1))
             if img is None:
-                if e8:
-                    if (k0, k1) != (0, lin.in_features):
-                        raise ParrotHipError("stream engine: an LLM.int8 Linear is not split into K-chunks")
-                    img = e8_image(lin, partner)  # (image, rows' scales)
-                    self.images.append(img[1])
-                else:
-                    img = e4_image(lin, partner, k0, k1) if e4 else e16_image(lin, partner, k0, k1)
+                def stamp(m):  # what the image was built from: a later load / .to() / optimiser step moves it on
+                    return None if m is None else ((id(m), m.image_epoch) if e4 else (id(m), m.weight.data_ptr(), m.weight._version))
+                mkey = (stamp(lin), stamp(partner), k0, k1)
+                img = model_images.get(mkey)
+                if img is None:
+                    for old in [k for k in model_images if k[0][0] == id(lin) and k[2:] == (k0, k1)]:
+                        del model_images[old]  # an image of the same Linear from before its weights changed
+                    if e8:
+                        if (k0, k1) != (0, lin.in_features):
+                            raise ParrotHipError("stream engine: an LLM.int8 Linear is not split into K-chunks")
+                        img = e8_image(lin, partner)  # (image, rows' scales)
+                    else:
+                        img = e4_image(lin, partner, k0, k1) if e4 else e16_image(lin, partner, k0, k1)
+                    model_images[mkey] = img
                 images[(id(lin), k0, k1)] = img
+                if e8:
+                    self.images.append(img[1])
                 self.images.append(img[0] if e8 else img)
             if e8:
                 op.nq = (K + 2047) // 2048  # int8 units are 2048 columns

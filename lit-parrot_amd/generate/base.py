@@ -62,6 +62,12 @@ class DecodeSession:
             engine = StreamEngine.faster_than_multi_launch(model, max_seq_length, ENGINE_AUTO_MIN_WINDOW)
         if engine and StreamEngine.supported(model) is None:
             self.eng = StreamEngine(model, self.tokens, self.pos, self.caches, max_seq_length, greedy)
+        # One resident image of the int4 weights: W4K (the multi-launch step's and every prompt's format; the engine keeps
+        # its E4 copy beside it).  The reference-layout buffers are released; state_dict() / get_weight() rebuild them exactly.
+        if RELEASE_REFERENCE_BUFFERS:
+            for m in model.modules():
+                if hasattr(m, "release_reference"):
+                    m.release_reference()
 
 
     # one decode step = the launch sequence that gets captured
@@ -146,6 +152,9 @@ class DecodeSession:
 # 654 tokens/s behind a 512-token prompt.  "auto" picks by weight format and window size.
 ENGINE_DEFAULT = "auto"
 ENGINE_AUTO_MIN_WINDOW = 1024
+# A decode session frees the reference-layout copy of every GPTQ int4 Linear (quantize/gptq.py::release_reference): Llama-2-7B
+# int4 then holds 3.5 GB of weights instead of 7 (multi-launch step) and Falcon-40B int4 44 GB instead of 66 (engine: W4K + E4).
+RELEASE_REFERENCE_BUFFERS = True
 
 
 def _session(model: GPT, max_seq_length: int, max_tokens: int, greedy: bool,
@@ -162,6 +171,7 @@ def _session(model: GPT, max_seq_length: int, max_tokens: int, greedy: bool,
     )
     if stale:
         cache.pop(key, None)
+        sess = None  # (the old session's buffers go before the new one's are allocated)
         sess = DecodeSession(model, max_seq_length, max_tokens, greedy, sampler=sampler)
         cache[key] = sess
     return sess

@@ -7,7 +7,10 @@ optional ``bias``), ``pack_weight`` / ``get_weight`` / ``forward``.  Differences
     is per-channel only and drops the bias, gptq.py:255-264);
   * ``pack_weight`` rounds to nearest before the uint8 cast (the reference truncates, gptq.py:239, which is only
     right for inputs already on the grid);
-  * the kernel reads a repacked copy of the weights ("W4K") built once after loading.
+  * the kernel reads a repacked copy of the weights ("W4K") built once after loading.  A decode session
+    (generate/base.py) then RELEASES the reference-layout buffers (``release_reference``): W4K is the one resident image
+    of the weights, and ``state_dict()`` / ``get_weight()`` / a later ``.to()`` rebuild ``quant_weight`` / ``scales`` /
+    ``zeros`` from it with the exact inverse repack (bit for bit: tests/test_full_size_gpu.py).
 ``rtn_quantize`` is the round-to-nearest quantiser used for synthetic weights (find_params_weight semantics,
 gptq.py:317-347).
 """
@@ -37,10 +40,15 @@ class ColBlockQuantizedLinear(torch.nn.Module):
         self.register_buffer("zeros", torch.empty((out_features, n_groups)))
         self.register_buffer("bias", torch.empty((out_features,)) if bias else None)
         self._packed: Optional[torch.Tensor] = None  # W4K copy (device), rebuilt when the buffers change
+        self._released = False     # the reference-layout buffers are empty placeholders: W4K is the only image
+        self._ref_dtype = None     # dtype of scales / zeros while released
+        self.image_epoch = 0       # moves on whenever the weights may have changed (derived images are keyed by it)
 
     # -------------------------------------------------------------------------------------- format (torch ops)
     def pack_weight(self, weight: torch.Tensor) -> None:
         """Quantise ``weight`` (out, in) onto the grid given by ``scales``/``zeros`` and store the nibbles."""
+        self.restore_reference()
+        self.image_epoch += 1
         w = weight.to(device=self.quant_weight.device, dtype=torch.float32)
         g = torch.arange(self.in_features, device=w.device) // self.tile_cols
         q = torch.round(w / self.scales.float()[:, g] + self.zeros.float()[:, g]).clamp_(0, 15).to(torch.uint8)
@@ -49,22 +57,73 @@ class ColBlockQuantizedLinear(torch.nn.Module):
 
     def get_weight(self, dtype: torch.dtype = torch.float) -> torch.Tensor:
         """Dequantised (out, in) weight: (q - zero) * scale computed in ``dtype`` like the reference (:243-252)."""
-        qw = self.quant_weight
+        qw, scales, zeros = self.reference_buffers()
         q = torch.empty((self.out_features, self.in_features), dtype=dtype, device=qw.device)
         q[:, 0::2] = (qw & 0xF).to(dtype)
         q[:, 1::2] = (qw >> 4).to(dtype)
         g = torch.arange(self.in_features, device=qw.device) // self.tile_cols
-        q -= self.zeros.to(dtype)[:, g]
-        q *= self.scales.to(dtype)[:, g]
+        q -= zeros.to(dtype)[:, g]
+        q *= scales.to(dtype)[:, g]
         return q
 
+    # -------------------------------------------------------------------------------------- one resident image
+    def release_reference(self) -> bool:
+        """Free ``quant_weight`` / ``scales`` / ``zeros`` once the W4K image exists: it holds the same information (nibbles,
+        and bf16 {scale, zero} per group) and ``parrot_w4_repack`` direction 1 inverts it exactly.  Only when the stored
+        scales are bf16 (the image's precision); returns whether the buffers were released."""
+        if self._released:
+            return True
+        if not self.quant_weight.is_cuda or self.scales.dtype != torch.bfloat16 or self.zeros.dtype != torch.bfloat16:
+            return False
+        self.packed()
+        self._ref_dtype = self.scales.dtype
+        dev = self.quant_weight.device
+        self.quant_weight = torch.empty((0,), dtype=torch.uint8, device=dev)
+        self.scales = torch.empty((0,), dtype=self._ref_dtype, device=dev)
+        self.zeros = torch.empty((0,), dtype=self._ref_dtype, device=dev)
+        self._released = True
+        return True
+
+    def reference_buffers(self) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+        """(quant_weight, scales, zeros) in the reference's layout (quantize/gptq.py:216-226): the module's own buffers, or -
+        after ``release_reference`` - fresh tensors rebuilt from the W4K image (the caller drops them when done)."""
+        if not self._released:
+            return self.quant_weight, self.scales, self.zeros
+        dev = self._packed.device
+        n_groups = -(-self.in_features // self.tile_cols)
+        qw = torch.empty((self.in_features // 2, self.out_features), dtype=torch.uint8, device=dev).t()
+        scales = torch.empty((self.out_features, n_groups), dtype=torch.bfloat16, device=dev)
+        zeros = torch.empty((self.out_features, n_groups), dtype=torch.bfloat16, device=dev)
+        ops.w4_repack(qw, scales, zeros, self.out_features, self.in_features, self.tile_cols, self._packed, 1)
+        return qw, scales.to(self._ref_dtype), zeros.to(self._ref_dtype)
+
+    def restore_reference(self) -> None:
+        """Make the reference-layout buffers resident again (before they are modified, moved or loaded into)."""
+        if self._released:
+            qw, scales, zeros = self.reference_buffers()
+            self._released = False
+            self.quant_weight, self.scales, self.zeros = qw, scales, zeros
+
+    def _save_to_state_dict(self, destination, prefix, keep_vars):
+        # the state-dict contract (<name>.quant_weight / .scales / .zeros / .bias) holds whether or not the buffers are resident
+        if not self._released:
+            return super()._save_to_state_dict(destination, prefix, keep_vars)
+        qw, scales, zeros = self.reference_buffers()
+        destination[prefix + "quant_weight"], destination[prefix + "scales"], destination[prefix + "zeros"] = qw, scales, zeros
+        if self.bias is not None:
+            destination[prefix + "bias"] = self.bias if keep_vars else self.bias.detach()
+
     def _load_from_state_dict(self, *args, **kwargs) -> None:
+        self.restore_reference()
         super()._load_from_state_dict(*args, **kwargs)
         self._packed = None
+        self.image_epoch += 1
 
     def _apply(self, fn, *args, **kwargs):
         # .to(device) / .to(dtype): keep quant_weight's column-major layout and drop the derived copy
+        self.restore_reference()
         self._packed = None
+        self.image_epoch += 1
         qw = self.quant_weight
         out = super()._apply(fn, *args, **kwargs)
         if self.quant_weight.stride() != (1, self.out_features):
@@ -76,6 +135,7 @@ class ColBlockQuantizedLinear(torch.nn.Module):
     def packed(self) -> torch.Tensor:
         """The kernel-native W4K buffer, built on first use with the repack kernel."""
         if self._packed is None:
+            assert not self._released
             if not self.quant_weight.is_cuda:
                 raise ParrotHipError("ColBlockQuantizedLinear: move the module to the GPU before running it")
             nbytes = ops.w4_packed_bytes(self.out_features, self.in_features, self.tile_cols)

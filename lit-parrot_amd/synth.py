@@ -95,6 +95,7 @@ def build_synthetic_model(config: Config, mode=None, seed: int = 1234, device="c
             if module.bias is not None:
                 module.bias.zero_()
             module._packed = None
+            module.image_epoch += 1
             del w, q
         elif isinstance(module, torch.nn.Linear):
             w = torch.randn((module.out_features, module.in_features), generator=gen, device=dev) * 0.02

@@ -213,13 +213,66 @@ def test_llama2_7b_int4_lm_head_rows_against_float64(llama7b_int4):
 
 
 @torch.no_grad()
-def test_full_size_repack_round_trip(llama7b_int4):
-    head: ColBlockQuantizedLinear = llama7b_int4.lm_head
+def test_full_size_repack_round_trip_and_released_reference_buffers(llama7b_int4):
+    """The W4K image of a full-size matrix inverts exactly - and that is what a decode session relies on when it frees the
+    reference-layout buffers (quantize/gptq.py::release_reference): reference_buffers() and state_dict() give back the
+    original quant_weight / scales / zeros bit for bit, get_weight() the same dequantised rows."""
+    model = build_synthetic_model(Config.from_name("Llama-2-7b-hf", n_layer=1), "gptq.int4-g128", seed=77, device=DEV)
+    head: ColBlockQuantizedLinear = model.lm_head
     N, K, G = head.out_features, head.in_features, head.tile_cols
+    orig = tuple(t.clone() for t in (head.quant_weight, head.scales, head.zeros))
+    rows = head.get_weight(torch.float32)[:64].clone()
     qw2 = torch.zeros_like(head.quant_weight)
     s2, z2 = torch.zeros_like(head.scales), torch.zeros_like(head.zeros)
     ops.w4_repack(qw2, s2, z2, N, K, G, head.packed(), 1)
-    assert torch.equal(qw2, head.quant_weight) and torch.equal(s2, head.scales) and torch.equal(z2, head.zeros)
+    assert torch.equal(qw2, orig[0]) and torch.equal(s2, orig[1]) and torch.equal(z2, orig[2])
+    sess = gb.DecodeSession(model, 32, 32, greedy=True)  # releases the reference-layout buffers of every int4 Linear
+    assert head._released and head.quant_weight.numel() == 0 and head.scales.numel() == 0
+    got = head.reference_buffers()
+    assert got[0].stride() == (1, N) and all(torch.equal(a, b) for a, b in zip(got, orig))
+    sd = model.state_dict()
+    assert torch.equal(sd["lm_head.quant_weight"], orig[0]) and torch.equal(sd["lm_head.scales"], orig[1]) and torch.equal(sd["lm_head.zeros"], orig[2])
+    assert sd["lm_head.quant_weight"].stride() == (1, N)
+    assert torch.equal(head.get_weight(torch.float32)[:64], rows)
+    # loading the state dict back (the module restores its buffers first), then running: the same logits
+    prompt = synthetic_prompt(model.config, 8, seed=3).to(DEV)
+    a = sess.prefill(prompt).clone()
+    model.load_state_dict(sd, strict=True)
+    assert not head._released and torch.equal(head.quant_weight, orig[0])
+    model.reset_cache()
+    b = gb.DecodeSession(model, 32, 32, greedy=True).prefill(prompt)
+    assert torch.equal(a, b)
+    del model, sess
+    torch.cuda.empty_cache()
+
+
+@pytest.mark.parametrize("name,engine,limit", [("Llama-2-7b-hf", False, 1.1), ("Llama-2-7b-hf", True, 2.1), ("falcon-40b", "auto", 2.1)])
+@torch.no_grad()
+def test_one_resident_weight_image_per_executor(name, engine, limit):
+    """Device memory held after a DecodeSession exists, against the algorithmic weight bytes (int4 nibbles + group metadata of
+    every Linear, bench.py::token_bytes) + the bf16 embedding: the multi-launch step keeps ONE image of the weights (W4K:
+    <= 1.1 x); an engine session keeps W4K (every prompt's format) and E4 (<= 2.1 x; three copies before round 3: the
+    reference-layout buffers are released, quantize/gptq.py)."""
+    import bench
+
+    torch.cuda.empty_cache()
+    base = torch.cuda.memory_allocated(DEV)
+    cfg = Config.from_name(name)
+    model = build_synthetic_model(cfg, "gptq.int4-g128", seed=1234, device=DEV)
+    S = 256
+    sess = gb.DecodeSession(model, S, S, greedy=True, engine=engine)
+    sess.prefill(synthetic_prompt(cfg, 16, seed=1).to(DEV))  # (lazy W4K images exist from here on)
+    torch.cuda.synchronize()
+    held = torch.cuda.memory_allocated(DEV) - base
+    w_bytes, _ = bench.token_bytes(cfg, "gptq.int4-g128", 0)
+    kv = 2 * cfg.n_layer * cfg.n_query_groups * S * cfg.head_size * 2
+    model_bytes = w_bytes + cfg.padded_vocab_size * cfg.n_embd * 2
+    ratio = (held - kv) / model_bytes
+    print(f"{name} engine={sess.eng is not None}: {held / 2**30:.2f} GiB held, {model_bytes / 2**30:.2f} GiB algorithmic -> {ratio:.3f} x")
+    assert ratio <= limit, f"{name}: {ratio:.3f} x the algorithmic weight bytes resident (limit {limit})"
+    assert (sess.eng is not None) == (engine is not False)
+    del sess, model
+    torch.cuda.empty_cache()
 
 
 @torch.no_grad()
