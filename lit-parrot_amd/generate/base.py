@@ -114,6 +114,8 @@ class DecodeSession:
             return
         # warm-up outside capture (lazy W4K repacks, workspace allocations), restoring the loop state afterwards
         saved = (self.tokens.clone(), self.pos.clone(), [(k.clone(), v.clone()) for k, v in self.caches])
+        # (a sampling step draws from torch's generator: the warm-up below must not use up draws of the caller's seed)
+        rng = torch.cuda.get_rng_state(self.device) if self.sampler is not None else None
         side = torch.cuda.Stream(device=self.device)
         side.wait_stream(torch.cuda.current_stream(self.device))
         with torch.cuda.stream(side):
@@ -124,6 +126,8 @@ class DecodeSession:
         with torch.cuda.graph(graph):
             self._step()
         self.graph = graph
+        if rng is not None:
+            torch.cuda.set_rng_state(rng, self.device)
         self.tokens.copy_(saved[0])
         self.pos.copy_(saved[1])
         for (k, v), (k0, v0) in zip(self.caches, saved[2]):

@@ -226,6 +226,45 @@ def golden_generate(ref):
 
 
 @torch.no_grad()
+def golden_generate_bf16(ref):
+    """north_star: "token-for-token greedy match at bf16".  The reference's OWN bf16 greedy run of Pythia-160M (the model in
+    bfloat16 under set_default_dtype(bfloat16), as Fabric's bf16-true runs it: fp16 RoPE tables, bf16 KV caches): the 64
+    tokens, and per step the two largest logits of the row the token was drawn from (values and indices) - the margin that
+    says whether another correct bf16 pipeline may legitimately pick a different token there."""
+    from lit_parrot_amd.config import name_to_config, Config
+    from lit_parrot_amd.synth import synthetic_prompt, synthetic_state_dict
+
+    cfg_dict = dict(name_to_config["pythia-160m"])
+    my_cfg = Config(**cfg_dict)
+    sd = synthetic_state_dict(my_cfg, 1234)
+    prompt = synthetic_prompt(my_cfg, 128, 1234)
+    torch.set_default_dtype(torch.bfloat16)
+    try:
+        model = ref_model(ref, cfg_dict, sd, torch.bfloat16)
+        rows = []
+        inner = model.forward
+
+        def recording_forward(*a, **k):
+            out = inner(*a, **k)
+            rows.append(out[0, -1].float().clone())
+            return out
+
+        model.forward = recording_forward
+        torch.manual_seed(1234)
+        y = ref["generate"](model, prompt, 192, max_seq_length=192, temperature=1.0, top_k=1)
+    finally:
+        torch.set_default_dtype(torch.float32)
+    assert len(rows) == 64 and y.shape == (192,)
+    top = [r.topk(2) for r in rows]
+    out = {"prompt": prompt.numpy(), "tokens": y.numpy(),
+           "top2_values": np.stack([t.values.numpy() for t in top]).astype(np.float32),
+           "top2_indices": np.stack([t.indices.numpy() for t in top]).astype(np.int64)}
+    np.savez_compressed(OUT / "generate_bf16.npz", **out)
+    m = out["top2_values"][:, 0] - out["top2_values"][:, 1]
+    print("generate bf16", y[128:136].tolist(), "... steps with a zero top-2 margin:", int((m == 0).sum()))
+
+
+@torch.no_grad()
 def golden_chat(ref):
     """chat/base.py::generate (the streaming generator with multi-token stop sequences) on a tiny fp32 model, greedy.
     Stored: for every case the stop sequences and the list of yielded items (each item flattened to a list of ints)."""
@@ -353,10 +392,14 @@ if __name__ == "__main__":
     if "--chat-only" in sys.argv:
         golden_chat(ref)
         sys.exit(0)
+    if "--generate-bf16-only" in sys.argv:
+        golden_generate_bf16(ref)
+        sys.exit(0)
     golden_pieces(ref)
     golden_gptq(ref)
     golden_models(ref)
     golden_generate(ref)
+    golden_generate_bf16(ref)
     golden_chat(ref)
     golden_gptq_quantizer(ref)
     golden_convert(ref)

@@ -134,6 +134,23 @@ def test_generate_matches_reference_tokens(golden_dir):
     assert torch.equal(y3, torch.from_numpy(g["eos_tokens"])) and len(y3) == 128 + int(g["eos_first_index"])
 
 
+def test_generate_bf16_matches_the_reference_run(golden_dir):
+    """The reference's own bf16 greedy run of Pythia-160M (tests/golden/generate_bf16.npz): with the same seed the oracle's
+    bf16 generate() returns the same 64 tokens - ties between equal bf16 maxima are broken by the same multinomial draw -
+    and the two largest logits of every step are the reference's bit for bit."""
+    g = np.load(golden_dir / "generate_bf16.npz")
+    cfg = Config.from_name("pythia-160m")
+    sd = {k: v.to(torch.bfloat16) for k, v in synthetic_state_dict(cfg, 1234).items()}
+    model = om.OracleGPT(cfg, sd)
+    prompt = torch.from_numpy(g["prompt"])
+    rows = []
+    torch.manual_seed(1234)
+    y = om.generate(model, prompt, 192, 192, temperature=1.0, top_k=1, logits_log=rows)
+    assert torch.equal(y, torch.from_numpy(g["tokens"]))
+    top = torch.stack([r.float().topk(2).values for r in rows])
+    assert torch.equal(top, torch.from_numpy(g["top2_values"]))
+
+
 def test_sampled_generate_matches_reference(golden_dir):
     g = np.load(golden_dir / "generate.npz")
     cfg = Config.from_name("tiny-llama")
