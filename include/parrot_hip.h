@@ -179,11 +179,15 @@ int parrot_qkv_rope_kvappend(const void* qkv, int ldqkv, int M, const void* rope
                              int q_per_kv, int hs, int S, void* q_out, void* k_cache, void* v_cache,
                              void* stream);
 /* y[m] = softmax(q[m] k^T / sqrt(hs)) v over slots 0..min(*pos+m, S-1); y: [M][n_head*hs] bf16.
- * workspace: fp32, at least parrot_attn_workspace_floats(...) elements.              */
+ * workspace: fp32, at least parrot_attn_workspace_floats(...) elements.
+ * softmax_mode (this entry point and parrot_attn_fused_decode): 0 = the probabilities stay fp32 until the division (default:
+ * closest to the exact result); 1 = parity runs: as torch's CPU flash-attention kernel computes the bf16 reference
+ * (lit_gpt/model.py:256-275): p = exp(s - max over the key block) rounded to bf16 before P.V, the denominator from the
+ * unrounded p - one key block, so nsplit == 1 and S <= 512, else PARROT_EUNSUPPORTED.                                      */
 int64_t parrot_attn_workspace_floats(int M, int n_head, int hs, int nsplit);
 int parrot_attn_decode(const void* q, int M, const int32_t* pos, const void* k_cache,
                        const void* v_cache, int n_groups, int q_per_kv, int hs, int S, int nsplit,
-                       void* workspace, void* y, int ldy, void* stream);
+                       void* workspace, void* y, int ldy, int softmax_mode, void* stream);
 
 /* Prompt rows on the matrix cores: y[m] = softmax(q[m] k^T / sqrt(hs), keys 0 .. *pos + m) v for the M rows of one prefill call
  * (lit_gpt/model.py:256-275 with the causal mask of :126-128), flash-attention style (32 queries per wave, key blocks of 32,
@@ -200,7 +204,7 @@ int parrot_attn_prefill(const void* q, int M, const int32_t* pos, const void* k_
 int parrot_attn_fused_decode(const void* qkv, const void* rope_cos, const void* rope_sin, int n_elem,
                              const int32_t* pos, int n_groups, int q_per_kv, int hs, int S, int nsplit,
                              void* workspace, void* tickets, void* k_cache, void* v_cache, void* y,
-                             void* stream);
+                             int softmax_mode, void* stream);
 /* ---- small ops of the step ----------------------------------------------------------
  * x[m] = wte[tokens[(pos ? *pos : 0) + m]]   (lit_gpt/model.py:99)                    */
 int parrot_embedding(const void* wte, int d, const int64_t* tokens, const int32_t* pos, int M,

@@ -85,8 +85,8 @@ SIGNATURES = {
     "parrot_layernorm": (_i, [_vp, _i, _vp, _vp, _vp, _i, _i, _i, _f, _vp]),
     "parrot_qkv_rope_kvappend": (_i, [_vp, _i, _i, _vp, _vp, _i, _i, _vp, _i, _i, _i, _i, _vp, _vp, _vp, _vp]),
     "parrot_attn_workspace_floats": (_i64, [_i, _i, _i, _i]),
-    "parrot_attn_decode": (_i, [_vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _i, _vp]),
-    "parrot_attn_fused_decode": (_i, [_vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "parrot_attn_decode": (_i, [_vp, _i, _vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _vp, _i, _i, _vp]),
+    "parrot_attn_fused_decode": (_i, [_vp, _vp, _vp, _i, _vp, _i, _i, _i, _i, _i, _vp, _vp, _vp, _vp, _vp, _i, _vp]),
     "parrot_attn_prefill_scratch_elems": (_i64, [_i, _i, _i]),
     "parrot_attn_prefill": (_i, [_vp, _i, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp, _i, _vp]),
     "parrot_e4_bytes": (_i64, [_i, _i, _i]),

@@ -105,7 +105,15 @@ __device__ __forceinline__ float slot_allreduce(float v) {
 
 // partial state layout in the workspace: [M][n_head][nsplit][hs + 2] floats: acc[hs], m, l
 // HQ = query heads of the group processed in one pass over the K/V rows (1 for MHA, up to 4 for GQA/MQA)
-template <int HS, int HQ>
+//
+// PM ("softmax_mode 1", parity runs only): the softmax as torch's CPU flash-attention kernel computes it for the bf16 reference
+// (lit_gpt/model.py:256-275 -> scaled_dot_product_attention): the probabilities p = exp(s - max) are ROUNDED TO bf16 before
+// they multiply V, with the row maximum of the whole key block as the reference point (torch walks the keys in blocks of 512:
+// for windows up to 512 keys that is the global maximum, and this mode is refused beyond), while the denominator sums the
+// unrounded p; accurate expf.  It needs the maximum before the first product, hence a pass over the K rows (scores only) in
+// front of the normal one.  The default (PM = false) keeps p in fp32: closer to the exact result, further from the
+// reference's bits.
+template <int HS, int HQ, bool PM = false>
 __global__ void __launch_bounds__(kAttnWaves * 64)
 attn_decode_kernel(const bf16_t* __restrict__ q, const int32_t* __restrict__ pos_ptr, const bf16_t* __restrict__ k_cache,
                    const bf16_t* __restrict__ v_cache, int n_groups, int q_per_kv, int S, int nsplit,
@@ -148,6 +156,34 @@ attn_decode_kernel(const bf16_t* __restrict__ q, const int32_t* __restrict__ pos
 #pragma unroll
             for (int e = 0; e < 8; ++e) acc[hh][e] = 0.f;
         }
+        float gmax[HQ];  // PM: the maximum score over all the keys of this row and head
+        if constexpr (PM) {
+#pragma unroll
+            for (int hh = 0; hh < HQ; ++hh) gmax[hh] = -INFINITY;
+            for (int s0 = s_first; s0 < s_end; s0 += STRIDE) {
+                const uint4 kv = kc[(int64_t)min(s0 + sub, s_last) * LPR + dl];
+#pragma unroll
+                for (int hh = 0; hh < HQ; ++hh) {
+                    float p0 = dot2_bf16(kv.x, qp[hh][0], 0.f), p1 = dot2_bf16(kv.y, qp[hh][1], 0.f);
+                    p0 = dot2_bf16(kv.z, qp[hh][2], p0);
+                    p1 = dot2_bf16(kv.w, qp[hh][3], p1);
+                    if (s0 + sub < s_end) gmax[hh] = fmaxf(gmax[hh], group_sum<LPR>(p0 + p1) * scale);
+                    else (void)group_sum<LPR>(p0 + p1);
+                }
+            }
+            __syncthreads();  // (the previous head chunk's merge has finished reading sh_m)
+#pragma unroll
+            for (int hh = 0; hh < HQ; ++hh) {
+                gmax[hh] = slot_allreduce<LPR, true>(gmax[hh]);
+                if (lane == 0) sh_m[hh][wave] = gmax[hh];
+            }
+            __syncthreads();
+#pragma unroll
+            for (int hh = 0; hh < HQ; ++hh) {
+                for (int t = 0; t < kAttnWaves; ++t) gmax[hh] = fmaxf(gmax[hh], sh_m[hh][t]);
+                mrun[hh] = gmax[hh];
+            }
+        }
         auto step = [&](const uint4 kv, const uint4 vv, int s) {
             const bool ok = s < s_end;
             const uint32_t vd[4] = {vv.x, vv.y, vv.z, vv.w};
@@ -163,6 +199,14 @@ attn_decode_kernel(const bf16_t* __restrict__ q, const int32_t* __restrict__ pos
                 p0 = dot2_bf16(kv.z, qp[hh][2], p0);
                 p1 = dot2_bf16(kv.w, qp[hh][3], p1);
                 const float sc_ = ok ? group_sum<LPR>(p0 + p1) * scale : -INFINITY;
+                if constexpr (PM) {
+                    const float p = ok ? expf(sc_ - gmax[hh]) : 0.f;
+                    const float pr = rbf(p);  // the probability as the reference's P.V product sees it
+                    lrun[hh] += p;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) acc[hh][e] = fmaf(pr, vf[e], acc[hh][e]);
+                    continue;
+                }
                 const float mn = fmaxf(mrun[hh], sc_);
                 const float corr = (mn == -INFINITY) ? 1.f : __expf(mrun[hh] - mn);
                 const float p = (mn == -INFINITY) ? 0.f : __expf(sc_ - mn);
@@ -278,7 +322,7 @@ static unsigned long long* g_attn_dbg_host = nullptr;  // diagnostic build only:
 static constexpr unsigned long long* g_attn_dbg_host = nullptr;
 #endif
 
-template <int HS, int HQ, int WAVES>
+template <int HS, int HQ, int WAVES, bool PM = false>  // PM: "softmax_mode 1", see attn_decode_kernel
 __global__ void __launch_bounds__(WAVES * 64)
 attn_fused_decode_kernel(const bf16_t* __restrict__ qkv, const __half* __restrict__ rope_cos,
                          const __half* __restrict__ rope_sin, int n_elem, const int32_t* __restrict__ pos_ptr,
@@ -381,6 +425,36 @@ attn_fused_decode_kernel(const bf16_t* __restrict__ qkv, const __half* __restric
             for (int e = 0; e < 8; ++e) acc[hh][e] = 0.f;
         }
         const int s_last = max(s_end - 1, 0);
+        float gmax[HQ];  // PM: the maximum score over all the keys of this head
+        if constexpr (PM) {
+#pragma unroll
+            for (int hh = 0; hh < HQ; ++hh) gmax[hh] = -INFINITY;
+            for (int s0 = s_first; s0 < s_end; s0 += STRIDE) {
+                const int sk = min(s0 + sub, s_last);
+                uint4 kv = kc[(int64_t)sk * LPR + dl];
+                if (sk == slot_new) kv = knew;  // the row being appended by this launch
+#pragma unroll
+                for (int hh = 0; hh < HQ; ++hh) {
+                    float p0 = dot2_bf16(kv.x, qp[hh][0], 0.f), p1 = dot2_bf16(kv.y, qp[hh][1], 0.f);
+                    p0 = dot2_bf16(kv.z, qp[hh][2], p0);
+                    p1 = dot2_bf16(kv.w, qp[hh][3], p1);
+                    const float sc_ = group_sum<LPR>(p0 + p1) * scale;
+                    if (s0 + sub < s_end) gmax[hh] = fmaxf(gmax[hh], sc_);
+                }
+            }
+#pragma unroll
+            for (int hh = 0; hh < HQ; ++hh) {
+                gmax[hh] = slot_allreduce<LPR, true>(gmax[hh]);
+                if (lane == 0) sh_m[hh][wave] = gmax[hh];
+            }
+            __syncthreads();
+#pragma unroll
+            for (int hh = 0; hh < HQ; ++hh) {
+                for (int t = 0; t < WAVES; ++t) gmax[hh] = fmaxf(gmax[hh], sh_m[hh][t]);
+                mrun[hh] = gmax[hh];
+            }
+            __syncthreads();  // (sh_m is written again by the wave merge below)
+        }
         // one step = the STRIDE keys of the workgroup; this lane: key s, dims 8*dl .. 8*dl+7
         auto step = [&](uint4 kv, uint4 vv, int s) {
             const bool ok = s < s_end;
@@ -402,6 +476,14 @@ attn_fused_decode_kernel(const bf16_t* __restrict__ qkv, const __half* __restric
                 p0 = dot2_bf16(kv.z, qp[hh][2], p0);
                 p1 = dot2_bf16(kv.w, qp[hh][3], p1);
                 const float sc_ = ok ? group_sum<LPR>(p0 + p1) * scale : -INFINITY;  // a masked key never raises the maximum
+                if constexpr (PM) {
+                    const float p = ok ? expf(sc_ - gmax[hh]) : 0.f;
+                    const float pr = rbf(p);  // the probability as the reference's P.V product sees it
+                    lrun[hh] += p;
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) acc[hh][e] = fmaf(pr, vf[e], acc[hh][e]);
+                    continue;
+                }
                 const float mn = fmaxf(mrun[hh], sc_);
                 const float corr = (mn == -INFINITY) ? 1.f : __expf(mrun[hh] - mn);
                 const float p = (mn == -INFINITY) ? 0.f : __expf(sc_ - mn);
@@ -506,16 +588,22 @@ attn_fused_decode_kernel(const bf16_t* __restrict__ qkv, const __half* __restric
 template <int HS>
 static int attn_fused_launch(const void* qkv, const void* cosp, const void* sinp, int n_elem, const int32_t* pos,
                              void* k_cache, void* v_cache, int n_groups, int q_per_kv, int S, int nsplit, void* ws,
-                             void* tickets, void* y, hipStream_t st) {
+                             void* tickets, void* y, int softmax_mode, hipStream_t st) {
     const int hq = q_per_kv == 1 ? 1 : (q_per_kv == 2 ? 2 : 4);
     // 16 waves when a split holds more keys than 4 waves cover in two steps
     const int per = (S + nsplit - 1) / nsplit;
     const bool wide = per > 2 * kAttnWaves * (64 / (HS / 8));
     const dim3 grid(n_groups, nsplit, (q_per_kv + hq - 1) / hq), block((wide ? 16 : kAttnWaves) * 64);
-#define PARROT_FUSED_GO(HQV, WV)                                                                                        \
-    return launch(K_ATTN_FUSED, attn_fused_decode_kernel<HS, HQV, WV>, grid, block, 0, st, (const bf16_t*)qkv,          \
-                  (const __half*)cosp, (const __half*)sinp, n_elem, pos, (bf16_t*)k_cache, (bf16_t*)v_cache, n_groups,   \
-                  q_per_kv, S, nsplit, (float*)ws, (unsigned int*)tickets, (bf16_t*)y, g_attn_dbg_host)
+#define PARROT_FUSED_GO(HQV, WV)                                                                                            \
+    do {                                                                                                                    \
+        if (softmax_mode == 1)                                                                                              \
+            return launch(K_ATTN_FUSED, attn_fused_decode_kernel<HS, HQV, 16, true>, grid, dim3(16 * 64), 0, st, (const bf16_t*)qkv, \
+                          (const __half*)cosp, (const __half*)sinp, n_elem, pos, (bf16_t*)k_cache, (bf16_t*)v_cache, n_groups, \
+                          q_per_kv, S, nsplit, (float*)ws, (unsigned int*)tickets, (bf16_t*)y, g_attn_dbg_host);             \
+        return launch(K_ATTN_FUSED, attn_fused_decode_kernel<HS, HQV, WV>, grid, block, 0, st, (const bf16_t*)qkv,          \
+                      (const __half*)cosp, (const __half*)sinp, n_elem, pos, (bf16_t*)k_cache, (bf16_t*)v_cache, n_groups,   \
+                      q_per_kv, S, nsplit, (float*)ws, (unsigned int*)tickets, (bf16_t*)y, g_attn_dbg_host);                 \
+    } while (0)
     if (wide) {
         if (q_per_kv == 1) PARROT_FUSED_GO(1, 16);
         if (q_per_kv == 2) PARROT_FUSED_GO(2, 16);
@@ -529,11 +617,14 @@ static int attn_fused_launch(const void* qkv, const void* cosp, const void* sinp
 
 template <int HS>
 static int attn_launch(const void* q, int M, const int32_t* pos, const void* k_cache, const void* v_cache, int n_groups,
-                       int q_per_kv, int S, int nsplit, void* ws, void* y, int ldy, hipStream_t st) {
+                       int q_per_kv, int S, int nsplit, void* ws, void* y, int ldy, int softmax_mode, hipStream_t st) {
     const dim3 grid(n_groups, nsplit, M), block(kAttnWaves * 64);
     int rc;
 #define PARROT_ATTN_GO(HQV)                                                                                          \
-    rc = launch(K_ATTN_DECODE, attn_decode_kernel<HS, HQV>, grid, block, 0, st, (const bf16_t*)q, pos,                \
+    rc = softmax_mode == 1                                                                                            \
+        ? launch(K_ATTN_DECODE, attn_decode_kernel<HS, HQV, true>, grid, block, 0, st, (const bf16_t*)q, pos,         \
+                 (const bf16_t*)k_cache, (const bf16_t*)v_cache, n_groups, q_per_kv, S, nsplit, (float*)ws, (bf16_t*)y, ldy) \
+        : launch(K_ATTN_DECODE, attn_decode_kernel<HS, HQV>, grid, block, 0, st, (const bf16_t*)q, pos,                \
                 (const bf16_t*)k_cache, (const bf16_t*)v_cache, n_groups, q_per_kv, S, nsplit, (float*)ws, (bf16_t*)y, ldy)
     if (q_per_kv == 1) {
         PARROT_ATTN_GO(1);
@@ -577,9 +668,21 @@ int parrot_tune_attn_stamps(void* dbg8_u64) {  // diagnostic build: device buffe
 }
 #endif
 
+// softmax_mode 1 needs the whole window in one key block of the reference's kernel: one split, at most 512 slots
+static int check_softmax_mode(const char* who, int softmax_mode, int S, int nsplit) {
+    PARROT_REQUIRE(softmax_mode == 0 || softmax_mode == 1, "%s: softmax_mode must be 0 or 1", who);
+    PARROT_UNSUPPORTED(softmax_mode == 0 || (nsplit == 1 && S <= 512),
+                       "%s: softmax_mode 1 (the reference's bf16 probabilities) is built for one split and windows up to 512 slots (S=%d nsplit=%d)", who, S, nsplit);
+    return PARROT_OK;
+}
+
 int parrot_attn_fused_decode(const void* qkv, const void* rope_cos, const void* rope_sin, int n_elem, const int32_t* pos,
                              int n_groups, int q_per_kv, int hs, int S, int nsplit, void* workspace, void* tickets,
-                             void* k_cache, void* v_cache, void* y, void* stream) {
+                             void* k_cache, void* v_cache, void* y, int softmax_mode, void* stream) {
+    {
+        const int rc = check_softmax_mode("attn_fused_decode", softmax_mode, S, nsplit);
+        if (rc != PARROT_OK) return rc;
+    }
     PARROT_REQUIRE(qkv && pos && k_cache && v_cache && y, "attn_fused_decode: null pointer");
     PARROT_REQUIRE(n_groups >= 1 && q_per_kv >= 1 && S >= 1, "attn_fused_decode: bad shape");
     PARROT_UNSUPPORTED(q_per_kv <= kFusedMaxQ, "attn_fused_decode: at most %d query heads per group (got %d)", kFusedMaxQ, q_per_kv);
@@ -590,9 +693,9 @@ int parrot_attn_fused_decode(const void* qkv, const void* rope_cos, const void* 
     PARROT_REQUIRE(aligned16(qkv) && aligned16(k_cache) && aligned16(v_cache), "attn_fused_decode: 16-byte alignment");
     hipStream_t st = (hipStream_t)stream;
     switch (hs) {
-        case 32: return attn_fused_launch<32>(qkv, rope_cos, rope_sin, n_elem, pos, k_cache, v_cache, n_groups, q_per_kv, S, nsplit, workspace, tickets, y, st);
-        case 64: return attn_fused_launch<64>(qkv, rope_cos, rope_sin, n_elem, pos, k_cache, v_cache, n_groups, q_per_kv, S, nsplit, workspace, tickets, y, st);
-        case 128: return attn_fused_launch<128>(qkv, rope_cos, rope_sin, n_elem, pos, k_cache, v_cache, n_groups, q_per_kv, S, nsplit, workspace, tickets, y, st);
+        case 32: return attn_fused_launch<32>(qkv, rope_cos, rope_sin, n_elem, pos, k_cache, v_cache, n_groups, q_per_kv, S, nsplit, workspace, tickets, y, softmax_mode, st);
+        case 64: return attn_fused_launch<64>(qkv, rope_cos, rope_sin, n_elem, pos, k_cache, v_cache, n_groups, q_per_kv, S, nsplit, workspace, tickets, y, softmax_mode, st);
+        case 128: return attn_fused_launch<128>(qkv, rope_cos, rope_sin, n_elem, pos, k_cache, v_cache, n_groups, q_per_kv, S, nsplit, workspace, tickets, y, softmax_mode, st);
         default: break;
     }
     set_error("attn_fused_decode: head size %d not built (32, 64, 128)", hs);
@@ -604,7 +707,11 @@ int64_t parrot_attn_workspace_floats(int M, int n_head, int hs, int nsplit) {
 }
 
 int parrot_attn_decode(const void* q, int M, const int32_t* pos, const void* k_cache, const void* v_cache, int n_groups,
-                       int q_per_kv, int hs, int S, int nsplit, void* workspace, void* y, int ldy, void* stream) {
+                       int q_per_kv, int hs, int S, int nsplit, void* workspace, void* y, int ldy, int softmax_mode, void* stream) {
+    {
+        const int rc = check_softmax_mode("attn_decode", softmax_mode, S, nsplit);
+        if (rc != PARROT_OK) return rc;
+    }
     PARROT_REQUIRE(q && pos && k_cache && v_cache && y, "attn_decode: null pointer");
     PARROT_REQUIRE(M >= 1 && n_groups >= 1 && q_per_kv >= 1 && S >= 1, "attn_decode: bad shape");
     PARROT_REQUIRE(nsplit >= 1 && nsplit <= 65535 && M <= 65535, "attn_decode: nsplit/M out of range");
@@ -613,9 +720,9 @@ int parrot_attn_decode(const void* q, int M, const int32_t* pos, const void* k_c
     PARROT_REQUIRE(aligned16(q) && aligned16(k_cache) && aligned16(v_cache), "attn_decode: q/k/v must be 16-byte aligned");
     hipStream_t st = (hipStream_t)stream;
     switch (hs) {
-        case 32: return attn_launch<32>(q, M, pos, k_cache, v_cache, n_groups, q_per_kv, S, nsplit, workspace, y, ldy, st);
-        case 64: return attn_launch<64>(q, M, pos, k_cache, v_cache, n_groups, q_per_kv, S, nsplit, workspace, y, ldy, st);
-        case 128: return attn_launch<128>(q, M, pos, k_cache, v_cache, n_groups, q_per_kv, S, nsplit, workspace, y, ldy, st);
+        case 32: return attn_launch<32>(q, M, pos, k_cache, v_cache, n_groups, q_per_kv, S, nsplit, workspace, y, ldy, softmax_mode, st);
+        case 64: return attn_launch<64>(q, M, pos, k_cache, v_cache, n_groups, q_per_kv, S, nsplit, workspace, y, ldy, softmax_mode, st);
+        case 128: return attn_launch<128>(q, M, pos, k_cache, v_cache, n_groups, q_per_kv, S, nsplit, workspace, y, ldy, softmax_mode, st);
         default: break;
     }
     set_error("attn_decode: head size %d not built (32, 64, 128)", hs);

@@ -275,6 +275,10 @@ def rope_kvappend(qkv: torch.Tensor, cos: torch.Tensor, sin: torch.Tensor, n_ele
                                                ptr(v_cache), stream()), "parrot_qkv_rope_kvappend")
 
 
+# 0: softmax probabilities in fp32 (default); 1: rounded to bf16 before P.V against the key block's maximum, as torch's CPU
+# flash-attention kernel computes the bf16 reference (parity runs: tests / tools/parity_table.py flip it);
+# windows up to 512 slots, the multi-launch step only (the engine's attention keeps fp32 probabilities)
+ATTN_SOFTMAX_MODE = 0
 FUSED_ATTN_MAX_Q_PER_KV = 16  # query heads per group the fused single-row kernel is built for
 ATTN_SPLIT_KEYS = 1024  # window slots per sequence split of the decode attention (bench.py --attn-split-keys: A/B)
 
@@ -304,7 +308,7 @@ def attn_decode(q: torch.Tensor, pos: torch.Tensor, k_cache: torch.Tensor, v_cac
     _rows(y, "attn_decode")
     M = y.shape[0]
     check(_hip.load().parrot_attn_decode(ptr(q), M, ptr(pos), ptr(k_cache), ptr(v_cache), n_groups, q_per_kv, hs, S,
-                                         nsplit, ptr(workspace), ptr(y), y.stride(0), stream()), "parrot_attn_decode")
+                                         nsplit, ptr(workspace), ptr(y), y.stride(0), ATTN_SOFTMAX_MODE, stream()), "parrot_attn_decode")
     return y
 
 
@@ -337,7 +341,7 @@ def attn_fused_decode(qkv: torch.Tensor, cos: torch.Tensor, sin: torch.Tensor, n
     lib = _hip.load()
     check(lib.parrot_attn_fused_decode(ptr(qkv), ptr(cos), ptr(sin), n_elem, ptr(pos), n_groups, q_per_kv, hs, S,
                                        nsplit, ptr(workspace), ptr(tickets), ptr(k_cache), ptr(v_cache), ptr(y),
-                                       stream()), "parrot_attn_fused_decode")
+                                       ATTN_SOFTMAX_MODE, stream()), "parrot_attn_fused_decode")
     return y
 
 

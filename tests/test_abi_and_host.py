@@ -38,7 +38,7 @@ def test_argument_validation_needs_no_gpu(hip_lib):
     assert hip_lib.parrot_w4_gemv(None, None, None, 0, 1, None, None, 0, None, 0, 8, 64, 64, 0, None, None) == -1
     assert "null pointer" in _hip.last_error()
     assert hip_lib.parrot_rmsnorm(None, 0, None, None, 0, 1, 64, 1e-5, 0, None) == -1
-    assert hip_lib.parrot_attn_decode(None, 1, None, None, None, 1, 1, 64, 8, 1, None, None, 0, None) == -1
+    assert hip_lib.parrot_attn_decode(None, 1, None, None, None, 1, 1, 64, 8, 1, None, None, 0, 0, None) == -1
     assert hip_lib.parrot_w4_packed_bytes(8, 100, 32) == -3  # K not a multiple of 32
     assert "multiple of 32" in _hip.last_error()
     assert hip_lib.parrot_kernel_name(0) == b"w4_gemv" and hip_lib.parrot_kernel_name(999) == b"?"

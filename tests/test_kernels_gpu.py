@@ -583,6 +583,49 @@ def test_rope_append_and_attention(n_groups, q_per_kv, hs, n_elem, S, nsplit):
         pos0 += rows
 
 
+@pytest.mark.parametrize("n_groups,q_per_kv,hs,n_elem", [(2, 1, 64, 64), (2, 2, 64, 64), (2, 1, 128, 128), (1, 4, 32, 32), (3, 1, 128, 32)])
+@pytest.mark.parametrize("S", [16, 300, 512])
+def test_softmax_mode_1_is_the_reference_kernels_arithmetic(n_groups, q_per_kv, hs, n_elem, S):
+    """softmax_mode 1 of parrot_attn_decode / parrot_attn_fused_decode against a float64 restatement of what torch's CPU flash
+    kernel does with bf16 operands: p = exp(s - rowmax) rounded to bf16 before P.V, the denominator from the unrounded p.
+    Heads within 1 bf16 ulp (the sums run in another order) and mostly bit-identical; both kernels agree with each other;
+    windows beyond one 512-key block are refused."""
+    g = gen(51)
+    n_head, width = n_groups * q_per_kv, n_groups * (q_per_kv + 2) * hs
+    cos, sin = (t.to(DEV) for t in om.rope_tables(2048, n_elem, BF, math_dtype=BF))
+    kc = torch.randn((n_groups, S, hs), generator=g).to(BF).to(DEV); vc = torch.randn((n_groups, S, hs), generator=g).to(BF).to(DEV)
+    kc2, vc2 = kc.clone(), vc.clone()
+    q = torch.empty((1, n_head * hs), dtype=BF, device=DEV)
+    y1, y2 = torch.empty_like(q), torch.empty_like(q)
+    ws = ops.attn_workspace(1, n_head, hs, 1, DEV)
+    tickets = torch.zeros((n_head,), dtype=torch.int32, device=DEV)
+    ops.ATTN_SOFTMAX_MODE = 1
+    try:
+        for pos in (0, 3, S - 2, S - 1):
+            qkv = torch.randn(1, width, generator=g).to(BF).to(DEV)
+            pos_d = torch.tensor([pos], dtype=torch.int32, device=DEV)
+            ops.rope_kvappend(qkv, cos, sin, n_elem, pos_d, n_groups, q_per_kv, hs, S, q, kc, vc)
+            ops.attn_decode(q, pos_d, kc, vc, n_groups, q_per_kv, hs, S, 1, ws, y1)
+            ops.attn_fused_decode(qkv, cos, sin, n_elem, pos_d, kc2, vc2, n_groups, q_per_kv, hs, S, 1, ws, tickets, y2)
+            assert torch.equal(kc, kc2) and torch.equal(vc, vc2)
+            n = pos + 1
+            qd = q.cpu().double().view(n_groups, q_per_kv, hs)
+            K, V = kc.cpu().double()[:, :n], vc.cpu().double()[:, :n]
+            sc = torch.einsum("gqd,gsd->gqs", qd, K).float() * (1.0 / math.sqrt(hs))  # fp32 scores, scaled after the dot
+            p = torch.exp(sc - sc.amax(dim=-1, keepdim=True))
+            want = torch.einsum("gqs,gsd->gqd", p.to(BF).double(), V) / p.double().sum(-1, keepdim=True)
+            for name_, got in (("attn_decode", y1), ("attn_fused_decode", y2)):
+                assert_bf16_close(got.view(-1), want.reshape(-1), ulps=1, atol=2e-3, what=f"{name_} softmax_mode 1, pos {pos}")
+                same = float((got.cpu().view(-1) == want.reshape(-1).to(BF)).float().mean())
+                assert same > 0.9, f"{name_} pos {pos}: only {same:.3f} bit-identical to the restated reference arithmetic"
+            assert float((y1 == y2).float().mean()) > 0.95
+        big = torch.zeros((n_groups, 513, hs), dtype=BF, device=DEV)
+        with pytest.raises(ParrotHipError, match="softmax_mode 1"):
+            ops.attn_decode(q, pos_d, big, big, n_groups, q_per_kv, hs, 513, 1, ws, y1)
+    finally:
+        ops.ATTN_SOFTMAX_MODE = 0
+
+
 def test_attention_ring_window_equals_rolled_cache():
     """pos >= S: slot = pos % S replaces the oldest key — the reference's roll-left + write-last (model.py:238-245)."""
     n_groups, q_per_kv, hs, n_elem, S = 2, 2, 64, 64, 10
