@@ -332,7 +332,12 @@ gemm2_w4_kernel(const bf16_t* __restrict__ A, int lda, int M, const uint4* __res
     const uint32_t cb_addr = lane * 4;
     int mt_, nt_, z_;
     g2_tile_of(mp, blockIdx.x, mt_, nt_, z_);
-    const int m0 = mt_ * G2M, n0 = nt_ * TN, zsplit = z_;
+    // SPLIT: the K range AND, for a SwiGLU pair, the matrix (fc_1 / fc_2) are grid dimensions - z = pass * ksplit + split: every
+    // workgroup makes ONE pass and writes one slab of partial sums.  (The pair used to run as a two-pass loop in the split kernel
+    // too: that variant needed 256 VGPRs + 14 - 16 spilled ones, 60 - 68 bytes of scratch per lane; the two-pass loop is now
+    // only in the unsplit kernel, which keeps the gate in registers for the fused epilogue.)
+    const int pass_begin = SPLIT ? z_ / ksplit : 0, pass_end = SPLIT ? pass_begin + 1 : (SWI ? 2 : 1);
+    const int m0 = mt_ * G2M, n0 = nt_ * TN, zsplit = SPLIT ? z_ - pass_begin * ksplit : 0;
     const int lr = lane & 31, lh = lane >> 5;
     const int ktiles = K / G2K;
     const int Gt = plan.Gs / 2;  // K-steps per quantisation group
@@ -372,8 +377,8 @@ gemm2_w4_kernel(const bf16_t* __restrict__ A, int lda, int M, const uint4* __res
 
     f32x16_t total[2][2];
     uint32_t gate[SWI && !SPLIT ? 2 : 1][SWI && !SPLIT ? 2 : 1][8];
-    const int npass = SWI ? 2 : 1;
-    for (int pass = 0; pass < npass; ++pass) {
+    static_assert(!(SPLIT && SWI), "a split SwiGLU pair runs the plain split kernel with the pass in the grid");
+    for (int pass = pass_begin; pass < pass_end; ++pass) {
         const uint4* Wp = pass ? Wq2 : Wq;
         f32x16_t acc[2][2];
 #pragma unroll
@@ -594,7 +599,8 @@ int gemm2_w4_launch(const void* Wq, const void* Wq2, const void* x, int ldx, int
     G2Map mp;
     mp.MT = (M + G2M - 1) / G2M;
     mp.NT = (N + wn * 64 - 1) / (wn * 64);
-    const int64_t total = (int64_t)mp.MT * mp.NT * ks;
+    const bool swi = epilogue == PARROT_EPI_SWIGLU;
+    const int64_t total = (int64_t)mp.MT * mp.NT * ks * (ks > 1 && swi ? 2 : 1);  // split SwiGLU pair: fc_1 and fc_2 as a grid dimension
     PARROT_UNSUPPORTED(total < (1ll << 31), "w4_gemm: too many tiles");
     const int resident_per_xcd = wn == 4 ? 32 : 64;
     mp.xcd_ok = (mp.NT % 8 == 0);
@@ -606,27 +612,17 @@ int gemm2_w4_launch(const void* Wq, const void* Wq2, const void* x, int ldx, int
                   M, (const uint4*)Wq, (const uint4*)Wq2, N, K, (const float*)workspace, Mpad, (const bf16_t*)bias, (const bf16_t*)residual, \
                   ldr, (bf16_t*)out, ldo, epilogue, plan, ks, part, part2, mp, (const uint32_t*)code)
 #define PARROT_G2W_GO(SPLITV, SWIV, WNV) PARROT_G2W_GO_CB(SPLITV, SWIV, WNV, false)
-    const bool swi = epilogue == PARROT_EPI_SWIGLU;
     if (code) {  // codebook weights: the 128 x 128 shape only
-        if (ks > 1) {
-            if (swi) PARROT_G2W_GO_CB(true, true, 2, true);
-            PARROT_G2W_GO_CB(true, false, 2, true);
-        }
+        if (ks > 1) PARROT_G2W_GO_CB(true, false, 2, true);
         if (swi) PARROT_G2W_GO_CB(false, true, 2, true);
         PARROT_G2W_GO_CB(false, false, 2, true);
     }
     if (wn == 4) {
-        if (ks > 1) {
-            if (swi) PARROT_G2W_GO(true, true, 4);
-            PARROT_G2W_GO(true, false, 4);
-        }
+        if (ks > 1) PARROT_G2W_GO(true, false, 4);
         if (swi) PARROT_G2W_GO(false, true, 4);
         PARROT_G2W_GO(false, false, 4);
     }
-    if (ks > 1) {
-        if (swi) PARROT_G2W_GO(true, true, 2);
-        PARROT_G2W_GO(true, false, 2);
-    }
+    if (ks > 1) PARROT_G2W_GO(true, false, 2);
     if (swi) PARROT_G2W_GO(false, true, 2);
     PARROT_G2W_GO(false, false, 2);
 #undef PARROT_G2W_GO
