@@ -225,7 +225,7 @@ def test_where_the_reference_bits_are_left(name, cpu_rsqrt_mode):
             ops.ATTN_SOFTMAX_MODE = 0
         heads_pm = ws.y.cpu()
         f_rows_pm = [float((heads_pm[r] == heads_ref[0, r]).float().mean()) for r in range(T)]
-        assert f_rows_pm[0] == 1.0 and min(f_rows_pm) >= 0.97 and sum(f_rows_pm) > sum(f_rows), (f_rows_pm, f_rows)
+        assert f_rows_pm[0] == 1.0 and min(f_rows_pm) >= 0.99 and sum(f_rows_pm) > sum(f_rows), (f_rows_pm, f_rows)  # measured: 1.0 on every row
         ws.y.copy_(heads_ref[0].to(DEV))
         ws.x.copy_(x_ref[0].to(DEV))
         _linear(blk.attn.proj, ws.y, ws.t, epilogue=EPI_RESIDUAL, residual=ws.x)
