@@ -118,6 +118,11 @@ constexpr uint64_t ENG_WAIT_TICKS = ENG_WAIT_TICKS_V;
 #ifndef ENG_STUB_HANDOFF
 #define ENG_STUB_HANDOFF 0
 #endif
+//   ENG_STUB_Q8 = 1       LLM.int8: the gather's activation quantiser does no per-element work (zeros, no outliers; its barrier and
+//                         LDS traffic stay): what the ~450 vector instructions per wave of the quantiser cost the token
+#ifndef ENG_STUB_Q8
+#define ENG_STUB_Q8 0
+#endif
 
 typedef parrot_eng_op_t EngOp;
 typedef parrot_eng_state_t EngState;
@@ -803,16 +808,24 @@ __device__ __forceinline__ void eng_gather(const EngState& st, const EngCtx& c0,
             // fused kernel): fp16 cast, entries with |a| >= threshold are outliers (kept in fp16, zero in the int8 copy,
             // excluded from the absmax), the others q = rint(a * (127 / absmax)).  LDS image: int8 [nq * 2048] then the
             // outlier list {column | fp16 << 16}, in a fixed order (wave, group round, lane, element).
+            // The quantiser sits on every hand-off's critical path (measured, round 3: with its per-element work stubbed the
+            // token takes 1739 us instead of 2124).  Outliers are rare - a handful of feature dimensions in a trained model, none
+            // at all in most 128-element groups - so both passes take a SHORT path for a wave's group without one: fp16
+            // magnitudes compare as 15-bit integers (a >= thr <=> its pattern >= that of the smallest fp16 >= thr; inf / NaN
+            // patterns are above every threshold), the absmax is an integer max3, no ballots, no prefix counts.  A group with
+            // an outlier (or an inf / NaN) anywhere in the wave takes the long path: the arithmetic below, unchanged.
             unsigned char* q8 = c.fx + ef_q8<CF>();
             const float thr = op->threshold;
+            const uint32_t thr16 = thr > 0.f ? (uint32_t)__half_as_ushort(__float2half_ru(thr)) : 0x7c00u;  // (no threshold: only inf / NaN leave the short path)
             uint32_t hv[CF::MAXG];
             float mx = 0.f;
+            uint32_t mxb = 0u;  // pattern of the largest magnitude seen on the short path
             int cnt = 0;
 #pragma unroll
             for (int i = 0; i < CF::MAXG; ++i) {
                 const int g = w.cw + CF::NC * i;
                 hv[i] = 0u;
-                if (g < ngr) {
+                if (!ENG_STUB_Q8 && g < ngr) {
                     uint32_t o = xv[i];
                     const int pr = 64 * g + c.lane;
                     if (na.kind != 0) {
@@ -824,6 +837,11 @@ __device__ __forceinline__ void eng_gather(const EngState& st, const EngCtx& c0,
                     if (pr >= npairs) o = 0u;
                     const __half h0 = __float2half(bflo(o)), h1 = __float2half(bfhi(o));
                     hv[i] = (uint32_t)__half_as_ushort(h0) | ((uint32_t)__half_as_ushort(h1) << 16);
+                    const uint32_t m0 = hv[i] & 0x7fffu, m1 = (hv[i] >> 16) & 0x7fffu;
+                    if (!__any(m0 >= thr16 || m1 >= thr16)) {
+                        mxb = max(mxb, max(m0, m1));
+                        continue;
+                    }
                     const float a0 = fabsf(__half2float(h0)), a1 = fabsf(__half2float(h1));
                     const bool o0 = thr > 0.f && a0 >= thr, o1 = thr > 0.f && a1 >= thr;
                     if (!o0) mx = fmaxf(mx, a0);
@@ -831,9 +849,16 @@ __device__ __forceinline__ void eng_gather(const EngState& st, const EngCtx& c0,
                     cnt += __popcll(__ballot(o0)) + __popcll(__ballot(o1));
                 }
             }
-            mx = wave_max(mx);
+            mx = fmaxf(mx, __half2float(__ushort_as_half((unsigned short)mxb)));
+            // (non-negative values: the DPP moves' zero fill is neutral; the wave's maximum lands in lane 63)
+            mx = fmaxf(mx, dpp0<0xB1>(mx));
+            mx = fmaxf(mx, dpp0<0x4E>(mx));
+            mx = fmaxf(mx, dpp0<0x141>(mx));
+            mx = fmaxf(mx, dpp0<0x140>(mx));
+            mx = fmaxf(mx, dpp0<0x142, 0xA>(mx));
+            mx = fmaxf(mx, dpp0<0x143, 0xC>(mx));
             const int eq_r = second ? EQ_ROUND2 : 0;  // this round's set of the waves' maxima / counts
-            if (c.lane == 0) {
+            if (c.lane == 63) {
                 reinterpret_cast<float*>(q8 + eq_r + EQ_MAX)[w.cw] = mx;
                 reinterpret_cast<int*>(q8 + eq_r + EQ_CNT)[w.cw] = cnt;
             }
@@ -857,9 +882,15 @@ __device__ __forceinline__ void eng_gather(const EngState& st, const EngCtx& c0,
 #pragma unroll
             for (int i = 0; i < CF::MAXG; ++i) {
                 const int g = w.cw + CF::NC * i;
-                if (g < op->nq * 16) {  // (the padding up to whole units is written as zeros)
+                if (ENG_STUB_Q8 && g < op->nq * 16) *reinterpret_cast<uint16_t*>(dstb + (64 * g + c.lane) * 2) = 0;
+                if (!ENG_STUB_Q8 && g < op->nq * 16) {  // (the padding up to whole units is written as zeros)
                     const float a0 = __half2float(__ushort_as_half((unsigned short)(hv[i] & 0xffffu)));
                     const float a1 = __half2float(__ushort_as_half((unsigned short)(hv[i] >> 16)));
+                    if (!__any((hv[i] & 0x7fffu) >= thr16 || ((hv[i] >> 16) & 0x7fffu) >= thr16)) {  // the short path: no outlier in the wave's group
+                        const int q0 = (int)rintf(__fmul_rn(a0, inv)), q1 = (int)rintf(__fmul_rn(a1, inv));
+                        *reinterpret_cast<uint16_t*>(dstb + (64 * g + c.lane) * 2) = (uint16_t)((q0 & 0xff) | ((q1 & 0xff) << 8));
+                        continue;
+                    }
                     const bool o0 = thr > 0.f && fabsf(a0) >= thr, o1 = thr > 0.f && fabsf(a1) >= thr;
                     const int q0 = o0 ? 0 : (int)rintf(__fmul_rn(a0, inv)), q1 = o1 ? 0 : (int)rintf(__fmul_rn(a1, inv));
                     *reinterpret_cast<uint16_t*>(dstb + (64 * g + c.lane) * 2) = (uint16_t)((q0 & 0xff) | ((q1 & 0xff) << 8));
