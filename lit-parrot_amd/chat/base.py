@@ -82,8 +82,14 @@ def _session(model: GPT, max_seq_length: int, max_tokens: int, greedy: bool, n_s
              or model.kv_caches[0][0].data_ptr() != sess.caches[0][0].data_ptr())
     if stale:
         cache.pop(key, None)
+        sess = None
+        from ..generate.base import MAX_SESSIONS_PER_MODEL
+        while len(cache) >= MAX_SESSIONS_PER_MODEL:
+            cache.pop(next(iter(cache)))
         sess = ChatSession(model, max_seq_length, max_tokens, greedy, sampler)
-        cache[key] = sess
+    else:
+        cache.pop(key)
+    cache[key] = sess
     return sess
 
 

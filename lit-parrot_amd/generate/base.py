@@ -159,6 +159,7 @@ ENGINE_AUTO_MIN_WINDOW = 1024
 # A decode session frees the reference-layout copy of every GPTQ int4 Linear (quantize/gptq.py::release_reference): Llama-2-7B
 # int4 then holds 3.5 GB of weights instead of 7 (multi-launch step) and Falcon-40B int4 44 GB instead of 66 (engine: W4K + E4).
 RELEASE_REFERENCE_BUFFERS = True
+MAX_SESSIONS_PER_MODEL = 4  # captured steps kept per model (keyed by window, greedy / sampling parameters), least recently used first out
 
 
 def _session(model: GPT, max_seq_length: int, max_tokens: int, greedy: bool,
@@ -176,8 +177,12 @@ def _session(model: GPT, max_seq_length: int, max_tokens: int, greedy: bool,
     if stale:
         cache.pop(key, None)
         sess = None  # (the old session's buffers go before the new one's are allocated)
+        while len(cache) >= MAX_SESSIONS_PER_MODEL:  # a caller that varies temperature / top_k per request must not pile up graphs
+            cache.pop(next(iter(cache)))
         sess = DecodeSession(model, max_seq_length, max_tokens, greedy, sampler=sampler)
-        cache[key] = sess
+    else:
+        cache.pop(key)  # (re-inserted below: the dict's order is the order of last use)
+    cache[key] = sess
     return sess
 
 

@@ -336,6 +336,27 @@ def test_greedy_generate_token_for_token(name):
     assert torch.equal(y, y3), "hipGraph replay and eager launches disagree"
 
 
+def test_captured_steps_per_model_are_bounded():
+    """A caller that changes temperature / top_k per request gets a captured step per setting; the model keeps the
+    MAX_SESSIONS_PER_MODEL most recently used ones, and coming back to a kept setting does not capture again."""
+    from lit_parrot_amd.generate import base as gb
+    cfg = Config.from_name("tiny-llama")
+    sd = {k: v.to(BF) for k, v in synthetic_state_dict(cfg, MODEL_SEED, perturb=True).items()}
+    model = hip_model(cfg, sd)
+    prompt = synthetic_prompt(cfg, 6, 3).to(DEV)
+    temps = [0.5 + 0.1 * i for i in range(gb.MAX_SESSIONS_PER_MODEL + 3)]
+    for t in temps:
+        torch.manual_seed(1)
+        L.generate(model, prompt, 12, 12, temperature=t, top_k=5)
+        assert len(model._decode_sessions) <= gb.MAX_SESSIONS_PER_MODEL
+    kept = list(model._decode_sessions)
+    assert [k[-1][0] for k in kept] == pytest.approx(temps[-gb.MAX_SESSIONS_PER_MODEL:])
+    first = model._decode_sessions[kept[0]]
+    torch.manual_seed(1)
+    L.generate(model, prompt, 12, 12, temperature=kept[0][-1][0], top_k=5)
+    assert model._decode_sessions[kept[0]] is first and list(model._decode_sessions)[-1] == kept[0]
+
+
 @pytest.mark.parametrize("engine", [False, True])
 def test_pythia160m_bf16_greedy_against_the_reference_bf16_run(golden_dir, engine):
     """BASELINE.json configs[0] on the GPU, north_star's "token-for-token greedy match at bf16": the judge is the REFERENCE's
