@@ -353,6 +353,7 @@ def main() -> None:
     ap.add_argument("--attn-split-keys", type=int, default=0, help="A/B: window slots per sequence split of the decode attention (default: the library's)")
     ap.add_argument("--engine", type=int, default=-1, help="1 / 0: force the one-launch stream engine on / off (default: the library's choice)")
     ap.add_argument("--no-sampled", action="store_true", help="skip the sampled-decode leg (generate's default call: temperature 0.8, top_k 200)")
+    ap.add_argument("--layers", type=int, default=0, help="diagnostic: build the workload's model with this many blocks (a cache-residency probe; the line is marked and is not the metric)")
     ap.add_argument("--watchdog", type=float, default=300.0, help="seconds without a phase change before the run reports where it is stuck and exits 3 (0: off)")
     args = ap.parse_args()
 
@@ -395,6 +396,8 @@ def main() -> None:
     wd = Watchdog(args.watchdog, tag=f"bench.py[{rank}]")
     cfg_name, mode, T, dtype_label = WORKLOADS[args.workload]
     cfg = Config.from_name(cfg_name)
+    if args.layers:
+        cfg.n_layer = args.layers
     total = T + args.warmup + args.steps + 1
     assert total <= cfg.block_size, "prompt + warmup + steps must fit block_size"
     t_build = time.perf_counter()
@@ -513,7 +516,8 @@ def main() -> None:
         "vs_baseline": None,
         "dtype": dtype_label,
         "data": "synthetic",
-        "config": {"workload": f"{cfg_name} {mode or 'bf16'} single-stream decode, {T}-token prompt, random-init weights",
+        "config": {"workload": f"{cfg_name} {mode or 'bf16'} single-stream decode, {T}-token prompt, random-init weights"
+                   + (f" - DIAGNOSTIC: {args.layers} of the model's blocks (not the metric)" if args.layers else ""),
                    "prompt_tokens": T, "replicas": world, "parallelism": f"replicas x{world} (no collective, no RCCL)",
                    "graph": "hipGraph replay per token"},
         "roofline": roofline,

@@ -12,9 +12,12 @@
 //        * the LDS image is lane-linear per instruction (hardware), so the bank-conflict swizzle is applied on the SOURCE
 //          side: 16-byte slot s of row r is stored at slot s ^ ((r >> 1) & 7) - rows are 128 B, two per 256-B bank row, and the
 //          16 rows a ds_read_b128 lane group touches land on 16 different 16-byte slots;
-//        * 4 waves as 2 x 2, each 64 x 64 = 2 x 2 tiles of v_mfma_f32_32x32x16_bf16, 16 MFMAs per wave and barrier.
+//        * waves as WM x 2, each 64 x 64 = 2 x 2 tiles of v_mfma_f32_32x32x16_bf16, 16 MFMAs per wave and barrier: 4 waves on
+//          a 128 x 128 tile, or 8 waves on a 256 x 128 tile with a ring of three (prompts of whole 256-row tiles).
 // Short launches (few 128 x 128 tiles) split K; the second stage (gemm.hip's fixed-order sum + epilogue) is shared.
 #include <stdlib.h>
+
+#include <type_traits>
 
 #include "parrot_common.h"
 #include "w4_plan.h"
@@ -57,46 +60,63 @@ __device__ __forceinline__ void g2_tile_of(const G2Map& mp, int id, int& mt, int
     nt = x * NTx + nb * mp.GN + r / mp.GM;
 }
 
-// G2_NBUF = LDS ring depth: 2 (64 KB, two workgroups per CU) or 3 (96 KB, one workgroup per CU, two tiles in flight)
-template <bool SPLIT, int G2_NBUF>
-__global__ void __launch_bounds__(256)
+// G2_NBUF = LDS ring depth, WM = wave rows of the tile (waves are WM x 2, each 64 x 64):
+//   WM = 2: 128 x 128 tile, 4 waves; ring of 2 (64 KB, two workgroups per CU) or 3 (96 KB, one per CU)
+//   WM = 4: 256 x 128 tile, 8 waves, ring of 3 (144 KB, one workgroup per CU): for prompts of 256 rows and more.  The 128 x 128
+//           shape loads 32 KB per 2 MFLOP-step and keeps ONE step per workgroup in flight (LDS holds no more twice per CU):
+//           at 512 rows it runs at the rate the operands arrive from L2 / the Infinity Cache (9.5 TB/s of tile loads = 64
+//           flop per byte = 600 TFLOP/s; profiles/r03b_stablelm*_kernel_stats.csv).  This shape loads 48 KB per 4 MFLOP
+//           (87 flop per byte) and keeps TWO steps (96 KB) in flight.
+template <bool SPLIT, int G2_NBUF, int WM>
+__global__ void __launch_bounds__(WM * 128)
 gemm2_kernel(const bf16_t* __restrict__ A, int lda, int M, const bf16_t* __restrict__ W, int N, int K,
              const bf16_t* __restrict__ bias, const bf16_t* residual, int ldr, bf16_t* out, int ldo, int epi, int ksplit,
              float* __restrict__ part, G2Map mp) {
+    constexpr int TM = WM * 64;                 // tile rows
+    constexpr int NWAVES = WM * 2;
+    constexpr int A16 = TM * 8;                 // 16-byte units of the A tile (TM rows x 128 B)
+    constexpr int STAGE16 = A16 + G2_TILE16;    // [A | B]
+    constexpr int A_LOADS = TM / 8 / NWAVES;    // LDS-DMA wave instructions (8 rows x 128 B each) per wave and K-step: 4
+    constexpr int B_LOADS = 16 / NWAVES;        // 4 (WM = 2) or 2 (WM = 4)
+    static_assert(A_LOADS * NWAVES * 8 == TM && B_LOADS * NWAVES == 16, "tile pieces must deal out evenly");
     // ONE LDS object (a second one beside an LDS-DMA target can cost a vmcnt(0) in front of every fragment read)
-    __shared__ __attribute__((aligned(1024))) uint4 smem[G2_NBUF][2][G2_TILE16];  // [buffer][A | B][row * 8 + slot]
+    __shared__ __attribute__((aligned(1024))) uint4 smem[G2_NBUF * STAGE16];  // [buffer][A rows | B rows][row * 8 + slot]
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
     int mt_, nt_, z_;
     g2_tile_of(mp, blockIdx.x, mt_, nt_, z_);
-    const int m0 = mt_ * G2M, n0 = nt_ * G2N, zsplit = z_;
+    const int m0 = mt_ * TM, n0 = nt_ * G2N, zsplit = z_;
     const int lr = lane & 31, lh = lane >> 5;
     const int ktiles = K / G2K;
     // split z owns K-steps [z * ktiles / ksplit, (z + 1) * ktiles / ksplit): the ranges need not be equal
     const int kt_begin = SPLIT ? (int)((int64_t)zsplit * ktiles / ksplit) : 0;
     const int kt_end = SPLIT ? (int)((int64_t)(zsplit + 1) * ktiles / ksplit) : ktiles;
 
-    // LDS-DMA assignment: a tile is 16 wave-instructions of 8 rows; wave w issues instructions 4w .. 4w+3 of A and of B.
+    // LDS-DMA assignment: wave w issues instructions w * A_LOADS .. of A and w * B_LOADS .. of B (8 rows each).
     // Lane l of an instruction: row r = r0 + l / 8, LDS slot l % 8 <- global slot (l % 8) ^ ((r >> 1) & 7).
     const int l_row = lane >> 3, l_slot = lane & 7;
-    const bf16_t* a_src[4];
-    const bf16_t* b_src[4];
+    const bf16_t* a_src[A_LOADS];
+    const bf16_t* b_src[B_LOADS];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int r = (wave * 4 + i) * 8 + l_row;
-        const int gs = l_slot ^ ((r >> 1) & 7);
-        a_src[i] = A + (int64_t)min(m0 + r, M - 1) * lda + gs * 8;
-        b_src[i] = W + (int64_t)min(n0 + r, N - 1) * K + gs * 8;
+    for (int i = 0; i < A_LOADS; ++i) {
+        const int r = (wave * A_LOADS + i) * 8 + l_row;
+        a_src[i] = A + (int64_t)min(m0 + r, M - 1) * lda + (l_slot ^ ((r >> 1) & 7)) * 8;
+    }
+#pragma unroll
+    for (int i = 0; i < B_LOADS; ++i) {
+        const int r = (wave * B_LOADS + i) * 8 + l_row;
+        b_src[i] = W + (int64_t)min(n0 + r, N - 1) * K + (l_slot ^ ((r >> 1) & 7)) * 8;
     }
     auto issue = [&](int kt, int buf) {
+        uint4* st = smem + buf * STAGE16;
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int r0 = (wave * 4 + i) * 8;
+        for (int i = 0; i < A_LOADS; ++i)
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a_src[i] + (int64_t)kt * G2K),
-                                             (__attribute__((address_space(3))) void*)&smem[buf][0][r0 * 8], 16, 0, 0);
+                                             (__attribute__((address_space(3))) void*)&st[(wave * A_LOADS + i) * 64], 16, 0, 0);
+#pragma unroll
+        for (int i = 0; i < B_LOADS; ++i)
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(b_src[i] + (int64_t)kt * G2K),
-                                             (__attribute__((address_space(3))) void*)&smem[buf][1][r0 * 8], 16, 0, 0);
-        }
+                                             (__attribute__((address_space(3))) void*)&st[A16 + (wave * B_LOADS + i) * 64], 16, 0, 0);
     };
 
     f32x16_t acc[2][2];
@@ -115,29 +135,35 @@ gemm2_kernel(const bf16_t* __restrict__ A, int lda, int M, const bf16_t* __restr
         b_row[i] = wn * 64 + i * 32 + lr;
     }
 
-    // Ring of G2_NBUF buffers.  An LDS-DMA load counts on vmcnt and retires in order (8 per wave and tile): before the
-    // barrier of step t every wave waits until at most the 8 loads of tile t+1 are outstanding, i.e. ITS pieces of tile t have
-    // landed; past the barrier everybody's have, and everybody is done reading the buffer of step t-1, which the loads of
-    // tile t+2 issued right behind the barrier overwrite.  A raw s_barrier: __syncthreads() would drain vmcnt(0).
+    // Ring of G2_NBUF buffers.  An LDS-DMA load counts on vmcnt and retires in order (A_LOADS + B_LOADS per wave and tile):
+    // before the barrier of step t every wave waits until at most the loads of tile t+1 are outstanding, i.e. ITS pieces of
+    // tile t have landed; past the barrier everybody's have, and everybody is done reading the buffer of step t-1, which the
+    // loads of tile t+2 issued right behind the barrier overwrite.  A raw s_barrier: __syncthreads() would drain vmcnt(0).
     issue(kt_begin, 0);
     if (G2_NBUF > 2 && kt_begin + 1 < kt_end) issue(kt_begin + 1, 1);
     int buf = 0;
     for (int kt = kt_begin; kt < kt_end; ++kt) {
-        if (G2_NBUF > 2 && kt + 1 < kt_end)
-            asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-        else
+        if (G2_NBUF > 2 && kt + 1 < kt_end) {
+            if constexpr (A_LOADS + B_LOADS == 8)
+                asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            else
+                asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        } else {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
         if (kt + G2_NBUF - 1 < kt_end) issue(kt + G2_NBUF - 1, buf >= 1 ? buf - 1 : G2_NBUF - 1);  // (buf + NBUF - 1) % NBUF
+        const uint4* sa = smem + buf * STAGE16;
+        const uint4* sb = sa + A16;
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks) {
             const int slot = ks * 2 + lh;
             bf16x8_t af[2], bfr[2];
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
-                af[i] = __builtin_bit_cast(bf16x8_t, smem[buf][0][a_row[i] * 8 + (slot ^ ((a_row[i] >> 1) & 7))]);
-                bfr[i] = __builtin_bit_cast(bf16x8_t, smem[buf][1][b_row[i] * 8 + (slot ^ ((b_row[i] >> 1) & 7))]);
+                af[i] = __builtin_bit_cast(bf16x8_t, sa[a_row[i] * 8 + (slot ^ ((a_row[i] >> 1) & 7))]);
+                bfr[i] = __builtin_bit_cast(bf16x8_t, sb[b_row[i] * 8 + (slot ^ ((b_row[i] >> 1) & 7))]);
             }
             if (G2_PRIO) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
@@ -168,13 +194,22 @@ gemm2_kernel(const bf16_t* __restrict__ A, int lda, int M, const bf16_t* __restr
         }
 }
 
-// K splits when the 128 x 128 tiles alone leave most of the chip idle: aim at ~256 - 512 workgroups, whole 64-deep steps,
-// at least 8 per split
+// tile rows: 256 (8 waves, one workgroup per CU) for prompts that fill whole 256-row tiles as well as 128-row ones
+int gemm2_wm(int M) {
+    const int env = tune_env("PARROT_GEMM2_WM", 0);  // PARROT_GEMM2_WM = 2 | 4 (A/B)
+    if (env == 2 || env == 4) return env;
+    return (M + 255) / 256 * 256 == (M + 127) / 128 * 128 ? 4 : 2;
+}
+
+// K splits when the tiles alone leave most of the chip idle: aim at ~512 workgroups of 128 x 128 (two fit a CU) or 256 of
+// 256 x 128 (one per CU), whole 64-deep steps, at least 8 per split
 int gemm2_ksplit(int M, int N, int K) {
-    const int64_t tiles = (int64_t)((M + G2M - 1) / G2M) * ((N + G2N - 1) / G2N);
+    const int wm = gemm2_wm(M), tm = wm * 64;
+    const int64_t tiles = (int64_t)((M + tm - 1) / tm) * ((N + G2N - 1) / G2N);
     const int ktiles = K / G2K;
-    const int target = tune_env("PARROT_GEMM2_SPLIT_TARGET", 512);  // PARROT_GEMM2_SPLIT_TARGET: workgroups to aim at when splitting (two fit on a CU: 512 fill the chip)
-    int ks = tiles > 256 ? 1 : (int)(target / (tiles > 0 ? tiles : 1));  // up to 256 tiles: split, two workgroups fit a CU
+    const int target = tune_env("PARROT_GEMM2_SPLIT_TARGET", wm == 4 ? 256 : 512);  // PARROT_GEMM2_SPLIT_TARGET: workgroups to aim at when splitting
+    const int full = wm == 4 ? 128 : 256;  // more tiles than this: no split
+    int ks = tiles > full ? 1 : (int)(target / (tiles > 0 ? tiles : 1));
     if (ks > 8) ks = 8;
     while (ks > 1 && ktiles / ks < 8) --ks;  // (uneven ranges are fine: split z owns steps [z kt / ks, (z + 1) kt / ks))
     return ks < 1 ? 1 : ks;
@@ -197,27 +232,32 @@ int gemm2_launch(const void* W, const void* x, int ldx, int M, const void* bias,
     const int ks = gemm2_ksplit(M, N, K);
     *ksplit_out = ks;
     PARROT_REQUIRE(ks == 1 || part != nullptr, "bf16_gemm: this shape splits K %d ways and needs the workspace of parrot_gemm_workspace_floats", ks);
+    const int wm = gemm2_wm(M), tm = wm * 64;
     G2Map mp;
-    mp.MT = (M + G2M - 1) / G2M;
+    mp.MT = (M + tm - 1) / tm;
     mp.NT = (N + G2N - 1) / G2N;
     const int64_t total = (int64_t)mp.MT * mp.NT * ks;
     PARROT_UNSUPPORTED(total < (1ll << 31), "bf16_gemm: too many tiles");
     // measured (tools/ab_gemm2.sh, StableLM-3B): 2 x 2-deep beats the 3-deep ring at one workgroup per CU at 512 and at 2048 rows
-    const int nbuf = nbuf_env == 3 ? 3 : 2;
+    const int nbuf = wm == 4 || nbuf_env == 3 ? 3 : 2;
     const int resident_per_xcd = nbuf == 3 ? 32 : 64;
     mp.xcd_ok = (mp.NT % 8 == 0);
     mp.GM = g2_largest_divisor_le(mp.MT, 8);
     mp.GN = mp.xcd_ok ? g2_largest_divisor_le(mp.NT / 8, resident_per_xcd / mp.GM > 0 ? resident_per_xcd / mp.GM : 1) : 1;
     const dim3 grid((unsigned)total);
-#define PARROT_G2_GO(SPLITV, NBUFV)                                                                                          \
-    return launch(K_BF16_GEMM, gemm2_kernel<SPLITV, NBUFV>, grid, dim3(256), 0, st, (const bf16_t*)x, ldx, M, (const bf16_t*)W, N, K, \
+#define PARROT_G2_GO(SPLITV, NBUFV, WMV)                                                                                      \
+    return launch(K_BF16_GEMM, gemm2_kernel<SPLITV, NBUFV, WMV>, grid, dim3(WMV * 128), 0, st, (const bf16_t*)x, ldx, M, (const bf16_t*)W, N, K, \
                   (const bf16_t*)bias, (const bf16_t*)residual, ldr, (bf16_t*)out, ldo, epilogue, ks, part, mp)
-    if (ks > 1) {
-        if (nbuf == 3) PARROT_G2_GO(true, 3);
-        PARROT_G2_GO(true, 2);
+    if (wm == 4) {
+        if (ks > 1) PARROT_G2_GO(true, 3, 4);
+        PARROT_G2_GO(false, 3, 4);
     }
-    if (nbuf == 3) PARROT_G2_GO(false, 3);
-    PARROT_G2_GO(false, 2);
+    if (ks > 1) {
+        if (nbuf == 3) PARROT_G2_GO(true, 3, 2);
+        PARROT_G2_GO(true, 2, 2);
+    }
+    if (nbuf == 3) PARROT_G2_GO(false, 3, 2);
+    PARROT_G2_GO(false, 2, 2);
 #undef PARROT_G2_GO
 }
 
@@ -378,6 +418,26 @@ gemm2_w4_kernel(const bf16_t* __restrict__ A, int lda, int M, const uint4* __res
     f32x16_t total[2][2];
     uint32_t gate[SWI && !SPLIT ? 2 : 1][SWI && !SPLIT ? 2 : 1][8];
     static_assert(!(SPLIT && SWI), "a split SwiGLU pair runs the plain split kernel with the pass in the grid");
+    // The K loop is bound by instruction ISSUE, not by the matrix pipe (16 MFMAs per wave and step are 512 pipe cycles; the first
+    // version of this loop issued 512 instructions per step - 203 scalar ones for slab walks, 64-bit addresses and M0 saves,
+    // 64 v_mov to restart the accumulators - and one wave issues one instruction per 4 cycles: 1.0 us per step, measured alone
+    // on a CU and no better with two workgroups, profiles/r03a).  So: per-lane 32-bit offsets against wave-uniform 64-bit
+    // bases that advance by scalar adds (saddr form of the LDS-DMA), one asm statement per tile with M0 stepped in place, slab
+    // and metadata positions kept as cursors, the K loop nested by quantisation group so that a group's first step starts its
+    // accumulators with a zero-C MFMA (no v_mov), and (x >> s) & mask | magic as shift + v_and_or_b32.
+    const uint32_t b_off = (uint32_t)(bl_rec * 16);
+    uint32_t a_off[A_PER_WAVE];
+#pragma unroll
+    for (int i = 0; i < A_PER_WAVE; ++i) a_off[i] = (uint32_t)((const char*)a_src[i] - (const char*)A);
+    const uint32_t lds0 = (uint32_t)(uintptr_t)smem;  // LDS byte address of stage 0 (wave-uniform)
+    const uint32_t mask4 = 0x000F000Fu;
+    // The expansion is written in plain C with the magic constant hidden in a VGPR, so that hipcc selects v_and_or_b32 (one
+    // literal operand) ITSELF.  The same instruction issued from inline asm (w4_plan.h and_or, fine in front of a dot2) is
+    // invisible to the compiler's hazard recognizer: an MFMA that read its B operand one wait state behind the asm's write got
+    // the old register - run-to-run different results in exactly the sub-tile whose MFMA follows the expansion (found with
+    // tools/probes/w4_gemm_repeat2.py; the compiler puts the wait states in when it sees the VALU write).
+    uint32_t magic = 0x43004300u;
+    asm("" : "+v"(magic));
     for (int pass = pass_begin; pass < pass_end; ++pass) {
         const uint4* Wp = pass ? Wq2 : Wq;
         f32x16_t acc[2][2];
@@ -387,24 +447,64 @@ gemm2_w4_kernel(const bf16_t* __restrict__ A, int lda, int M, const uint4* __res
             for (int j = 0; j < 2; ++j)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[i][j][r] = total[i][j][r] = 0.f;
-        int slab = 0;  // slab of the K-step being issued (issue order is monotone)
-        auto issue_tile = [&](int kt, int buf) {
-            while (slab + 1 < plan.nslabs && 2 * kt >= plan.slab[slab + 1].slice0) ++slab;
-            uint4* st = smem + buf * W4_STAGE16;
+        // ---- issue cursors (wave-uniform): the next K-step to issue, its slab, the byte positions of its A columns / B slices
+        int i_slab = 0;
+        while (i_slab + 1 < plan.nslabs && 2 * kt_begin >= plan.slab[i_slab + 1].slice0) ++i_slab;
+        int i_next = i_slab + 1 < plan.nslabs ? plan.slab[i_slab + 1].slice0 : 0x7fffffff;  // first slice of the next slab
+        int kt_issue = kt_begin;
+        const char* a_ptr = reinterpret_cast<const char*>(A) + (int64_t)kt_begin * (G2K * 2);
+        const char* b_ptr = reinterpret_cast<const char*>(Wp + plan.slab[i_slab].w_off16 + (2 * kt_begin - plan.slab[i_slab].slice0));
+        auto issue_tile = [&](int buf) {
+            if (2 * kt_issue >= i_next) {  // (rare: a slab holds up to 32 K-steps)
+                ++i_slab;
+                i_next = i_slab + 1 < plan.nslabs ? plan.slab[i_slab + 1].slice0 : 0x7fffffff;
+                b_ptr = reinterpret_cast<const char*>(Wp + plan.slab[i_slab].w_off16);
+            }
+            const uint32_t st = lds0 + (uint32_t)buf * (W4_STAGE16 * 16);
+            const uint32_t da = __builtin_amdgcn_readfirstlane(st + (uint32_t)wave * (A_PER_WAVE * 1024));
+            const uint32_t db = __builtin_amdgcn_readfirstlane(st + G2_TILE16 * 16 + (uint32_t)wave * 1024);
+            unsigned keep;
+#ifndef G2W_OLD_ISSUE
+            if constexpr (A_PER_WAVE == 4)
+                asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\t"
+                             "global_load_lds_dwordx4 %3, %7\n\ts_add_u32 m0, m0, 0x400\n\ts_nop 0\n\t"
+                             "global_load_lds_dwordx4 %4, %7\n\ts_add_u32 m0, m0, 0x400\n\ts_nop 0\n\t"
+                             "global_load_lds_dwordx4 %5, %7\n\ts_add_u32 m0, m0, 0x400\n\ts_nop 0\n\t"
+                             "global_load_lds_dwordx4 %6, %7\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\t"
+                             "global_load_lds_dwordx4 %8, %9\n\ts_mov_b32 m0, %0"
+                             : "=&s"(keep)
+                             : "s"(da), "s"(db), "v"(a_off[0]), "v"(a_off[1]), "v"(a_off[A_PER_WAVE > 2 ? 2 : 0]),
+                               "v"(a_off[A_PER_WAVE > 3 ? 3 : 0]), "s"(a_ptr), "v"(b_off), "s"(b_ptr)
+                             : "memory", "scc");
+            else
+                asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\t"
+                             "global_load_lds_dwordx4 %3, %5\n\ts_add_u32 m0, m0, 0x400\n\ts_nop 0\n\t"
+                             "global_load_lds_dwordx4 %4, %5\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\t"
+                             "global_load_lds_dwordx4 %6, %7\n\ts_mov_b32 m0, %0"
+                             : "=&s"(keep)
+                             : "s"(da), "s"(db), "v"(a_off[0]), "v"(a_off[1]), "s"(a_ptr), "v"(b_off), "s"(b_ptr)
+                             : "memory", "scc");
+#else
+            {
+                uint4* stp = smem + buf * W4_STAGE16;
 #pragma unroll
-            for (int i = 0; i < A_PER_WAVE; ++i)
-                glds16_asm(a_src[i] + (int64_t)kt * G2K, st + (wave * A_PER_WAVE + i) * 64);
-            const uint4* bsrc = Wp + bl_rec + plan.slab[slab].w_off16 + (2 * kt - plan.slab[slab].slice0);
-            glds16_asm(bsrc, st + G2_TILE16 + wave * 64);
+                for (int i = 0; i < A_PER_WAVE; ++i) glds16_asm(a_ptr + a_off[i], stp + (wave * A_PER_WAVE + i) * 64);
+                glds16_asm(b_ptr + b_off, stp + G2_TILE16 + wave * 64);
+                (void)keep; (void)da; (void)db;
+            }
+#endif
+            a_ptr += G2K * 2;
+            b_ptr += 32;
+            ++kt_issue;
         };
+        int m_slab = i_slab;
         auto issue_meta = [&](int g) {  // one 4-byte LDS-DMA per wave
             uint4* mb = meta + (g & 1) * W4_META16;
             if (wave < 2) {
                 if constexpr (!CB) glds4_asm(xs_src + (int64_t)g * Mpad, reinterpret_cast<float*>(mb) + wave * 64);
             } else if (wave < 2 + WN) {
-                int gs = 0;
-                while (gs + 1 < plan.nslabs && 2 * g * Gt >= plan.slab[gs + 1].slice0) ++gs;
-                const uint32_t* msrc = reinterpret_cast<const uint32_t*>(Wp + ml_rec + plan.slab[gs].meta_off16) + (g - plan.slab[gs].g0);
+                while (m_slab + 1 < plan.nslabs && 2 * g * Gt >= plan.slab[m_slab + 1].slice0) ++m_slab;  // (groups are issued in order)
+                const uint32_t* msrc = reinterpret_cast<const uint32_t*>(Wp + ml_rec + plan.slab[m_slab].meta_off16) + (g - plan.slab[m_slab].g0);
                 glds4_asm(msrc, reinterpret_cast<uint32_t*>(mb + 32) + (wave - 2) * 64);
             }
         };
@@ -414,19 +514,21 @@ gemm2_w4_kernel(const bf16_t* __restrict__ A, int lda, int M, const uint4* __res
         // metadata of group g+1 is issued at the start of group g (before that step's tile, so that the newest loads are always
         // whole tiles) into the other parity, which the fold of group g-1 finished reading before this step's barrier.
         __syncthreads();  // previous pass done with the stages and the metadata
-        issue_meta(kt_begin / Gt);
+        const int g_begin = kt_begin / Gt;
+        issue_meta(g_begin);
 #pragma unroll
         for (int d = 0; d < W4_NBUF - 1; ++d)
-            if (kt_begin + d < kt_end) issue_tile(kt_begin + d, d);
-        int buf = 0;
-        for (int kt = kt_begin; kt < kt_end; ++kt) {
+            if (kt_begin + d < kt_end) issue_tile(d);
+        int buf = 0, kt = kt_begin;
+        auto step = [&](auto first_tag, int g) {
+            constexpr bool FIRST = decltype(first_tag)::value;
             // tiles still allowed in flight: min(NBUF - 2, steps left after this one); the count is an immediate
             const int ahead = min(W4_NBUF - 2, kt_end - 1 - kt);
-            if (ahead >= 4)
+            if (W4_NBUF > 5 && ahead >= 4)
                 asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * TILE_LOADS) : "memory");
-            else if (ahead == 3)
+            else if (W4_NBUF > 4 && ahead == 3)
                 asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * TILE_LOADS) : "memory");
-            else if (ahead == 2)
+            else if (W4_NBUF > 3 && ahead == 2)
                 asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * TILE_LOADS) : "memory");
             else if (ahead == 1)
                 asm volatile("s_waitcnt vmcnt(%0)" ::"n"(1 * TILE_LOADS) : "memory");
@@ -434,9 +536,8 @@ gemm2_w4_kernel(const bf16_t* __restrict__ A, int lda, int M, const uint4* __res
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
-            const int g = kt / Gt;
-            if (kt % Gt == 0 && g + 1 < g_end) issue_meta(g + 1);
-            if (kt + W4_NBUF - 1 < kt_end) issue_tile(kt + W4_NBUF - 1, buf >= 1 ? buf - 1 : W4_NBUF - 1);
+            if (FIRST && g + 1 < g_end) issue_meta(g + 1);
+            if (kt_issue < kt_end) issue_tile(buf >= 1 ? buf - 1 : W4_NBUF - 1);
             const uint4* sa = smem + buf * W4_STAGE16;
             const uint4* sb = sa + G2_TILE16;
             // this lane's 2 x 4 dwords of packed weights: k-block lh * 4 + ks of the step goes to MFMA ks (any assignment of the
@@ -455,16 +556,34 @@ gemm2_w4_kernel(const bf16_t* __restrict__ A, int lda, int M, const uint4* __res
                         w4c_dword_lookup(bw[i][ks], cb_addr, o);
                     } else {
 #pragma unroll
-                        for (int q = 0; q < 4; ++q) o[q] = ((bw[i][ks] >> (4 * q)) & 0x000F000Fu) | 0x43004300u;
+                        for (int q = 0; q < 4; ++q) o[q] = ((bw[i][ks] >> (4 * q)) & mask4) | magic;  // (plain C: see the note at `magic`)
                     }
                     bfr[i] = __builtin_bit_cast(bf16x8_t, make_uint4(o[0], o[1], o[2], o[3]));
                 }
 #pragma unroll
                 for (int i = 0; i < 2; ++i)
 #pragma unroll
-                    for (int j = 0; j < 2; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+                    for (int j = 0; j < 2; ++j) {
+#ifdef G2W_NO_ZEROC
+                        if (false) {
+#else
+                        if (FIRST && ks == 0) {  // the group's accumulators start here: C = 0 is an operand, not 64 v_mov
+#endif
+                            const f32x16_t zero = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], zero, 0, 0, 0);
+                        } else {
+                            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+                        }
+                    }
             }
-            if ((kt + 1) % Gt == 0 || kt + 1 == kt_end) {  // group end: fold
+            buf = buf + 1 == W4_NBUF ? 0 : buf + 1;
+            ++kt;
+        };
+        for (int g = g_begin; g < g_end; ++g) {
+            const int kg_end = min((g + 1) * Gt, kt_end);
+            step(std::true_type{}, g);
+            while (kt < kg_end) step(std::false_type{}, g);
+            {  // group end: fold
                 const uint4* mb = meta + (g & 1) * W4_META16;
                 const float* xs_l = reinterpret_cast<const float*>(mb);
                 const uint32_t* mt_l = reinterpret_cast<const uint32_t*>(mb + 32);
@@ -490,11 +609,12 @@ gemm2_w4_kernel(const bf16_t* __restrict__ A, int lda, int M, const uint4* __res
                                 const float xs = (r & 3) == 0 ? x4.x : ((r & 3) == 1 ? x4.y : ((r & 3) == 2 ? x4.z : x4.w));
                                 total[i][j][r] += sc * (acc[i][j][r] - zz * xs);
                             }
+#ifdef G2W_NO_ZEROC
                             acc[i][j][r] = 0.f;
+#endif
                         }
                 }
             }
-            buf = buf + 1 == W4_NBUF ? 0 : buf + 1;
         }
         if constexpr (SPLIT) {
             float* dst = (pass ? part2 : part) + (int64_t)zsplit * M * N;

@@ -228,6 +228,30 @@ def test_w4_gemm_lds_dma_kernel_unsplit_launch_and_single_step_groups(group, epi
     assert torch.all(out[M] == 7.0), "wrote past the last row"
 
 
+@pytest.mark.parametrize("epi", [EPI_NONE, EPI_SWIGLU])
+def test_w4_gemm_long_unsplit_loop_repeats_bit_identically(epi):
+    """The unsplit int4 prompt kernel over a long K loop (32 steps, a slab crossing), called four times on the same operands:
+    the same bits every time, and the right ones.  (An expansion issued from inline asm one wait state in front of the MFMA
+    that reads it gave run-to-run different results in one 32 x 32 sub-tile per wave - only in loops long enough for the
+    matrix pipe to run dry, which the 4-step launches of the test above never are.)"""
+    M, N, K, group = 640, 8192, 2048, 128
+    g = gen(41)
+    x = torch.randn(M, K, generator=g).to(BF)
+    qw, s, z, tc, Wd = make_w4(N, K, group, 42)
+    qw2, s2, z2, _, Wd2 = make_w4(N, K, group, 43)
+    lin, lin2 = w4_module(qw, s, z, N, K, group), w4_module(qw2, s2, z2, N, K, group)
+    outs = []
+    for rep in range(4):
+        out = torch.empty((M, N), dtype=BF, device=DEV)
+        lin.hip_linear(x.to(DEV), out, epilogue=epi, partner=lin2 if epi == EPI_SWIGLU else None)
+        outs.append(out)
+    for o in outs[1:]:
+        assert torch.equal(outs[0], o), f"{int((outs[0] != o).sum())} elements differ between two calls"
+    want = expected_epilogue(x.double() @ Wd.t(), x.double() @ Wd2.t() if epi == EPI_SWIGLU else None, None, None, epi)
+    assert_bf16_close(outs[0], want, ulps=1, atol=6e-2 if epi == EPI_SWIGLU else 1.5e-2, what=f"w4 gemm2 unsplit long K epi {epi}")
+    assert float((outs[0].cpu().double() - want).abs().mean()) < 3e-3
+
+
 @pytest.mark.parametrize("epi", [EPI_RESIDUAL, EPI_GELU, EPI_SWIGLU])
 @pytest.mark.parametrize("kind", ["w4", "bf16"])
 def test_gemm_epilogues(epi, kind):
