@@ -401,7 +401,11 @@ gemm2_w4_kernel(const bf16_t* __restrict__ A, int lda, int M, const uint4* __res
     // (one row each, same half) land on 16 different 16-byte slots
     const int bl_row = wave * 32 + (lane >> 1);
     const int bl_half = (lane & 1) ^ ((bl_row >> 3) & 1);
+#ifdef G2W_STUB_BSAME  // diagnostic: every workgroup streams the SAME 128 weight rows (L2 hits): is the loop waiting for B from HBM?
+    const int64_t bl_rec = (int64_t)bl_row * plan.row16 + bl_half;
+#else
     const int64_t bl_rec = (int64_t)min(n0 + bl_row, N - 1) * plan.row16 + bl_half;
+#endif
     // metadata: waves 0, 1 bring the activation sums of rows 64 w + lane, waves 2, 3 the {scale, zero} words of columns 64 (w - 2) + lane
     const int64_t ml_rec = (int64_t)min(n0 + max(wave - 2, 0) * 64 + lane, N - 1) * plan.row16;
     const float* xs_src = xsT + m0 + (wave & 1) * 64 + lane;
@@ -464,7 +468,9 @@ gemm2_w4_kernel(const bf16_t* __restrict__ A, int lda, int M, const uint4* __res
             const uint32_t da = __builtin_amdgcn_readfirstlane(st + (uint32_t)wave * (A_PER_WAVE * 1024));
             const uint32_t db = __builtin_amdgcn_readfirstlane(st + G2_TILE16 * 16 + (uint32_t)wave * 1024);
             unsigned keep;
-#ifndef G2W_OLD_ISSUE
+#ifdef G2W_STUB_NOLOAD
+            (void)keep; (void)da; (void)db;
+#elif !defined(G2W_OLD_ISSUE)
             if constexpr (A_PER_WAVE == 4)
                 asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\t"
                              "global_load_lds_dwordx4 %3, %7\n\ts_add_u32 m0, m0, 0x400\n\ts_nop 0\n\t"
@@ -564,6 +570,11 @@ gemm2_w4_kernel(const bf16_t* __restrict__ A, int lda, int M, const uint4* __res
                 for (int i = 0; i < 2; ++i)
 #pragma unroll
                     for (int j = 0; j < 2; ++j) {
+#ifdef G2W_STUB_NOMFMA
+                        if (true) {
+                            asm volatile("" ::"v"(af[i]), "v"(bfr[j]));
+                        } else
+#endif
 #ifdef G2W_NO_ZEROC
                         if (false) {
 #else
@@ -583,6 +594,7 @@ gemm2_w4_kernel(const bf16_t* __restrict__ A, int lda, int M, const uint4* __res
             const int kg_end = min((g + 1) * Gt, kt_end);
             step(std::true_type{}, g);
             while (kt < kg_end) step(std::false_type{}, g);
+#ifndef G2W_STUB_NOFOLD
             {  // group end: fold
                 const uint4* mb = meta + (g & 1) * W4_META16;
                 const float* xs_l = reinterpret_cast<const float*>(mb);
@@ -615,6 +627,12 @@ gemm2_w4_kernel(const bf16_t* __restrict__ A, int lda, int M, const uint4* __res
                         }
                 }
             }
+#else
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) total[i][j] += acc[i][j];
+#endif
         }
         if constexpr (SPLIT) {
             float* dst = (pass ? part2 : part) + (int64_t)zsplit * M * N;
