@@ -286,6 +286,45 @@ gemm_splitk_epilogue_kernel(const float* __restrict__ part, const float* __restr
     out[(int64_t)row * ldo + col] = o;
 }
 
+// the same with four columns per thread (16-byte loads of the partials, one 8-byte store): the launch is bound by its slab traffic
+// (ks x M x N x 4 bytes - 31 MB for the QKV Linear of Llama-2-7B at 128 rows), which one-float-per-lane loads move at half the rate
+__global__ void __launch_bounds__(256)
+gemm_splitk_epilogue4_kernel(const float* __restrict__ part, const float* __restrict__ part2, int ksplit, int M, int N,
+                             const bf16_t* __restrict__ bias, const bf16_t* residual, int ldr, bf16_t* out, int ldo, int epi) {
+    const unsigned bpr = (unsigned)(N + 1023) / 1024u;
+    const int row = (int)(blockIdx.x / bpr), col = ((int)(blockIdx.x % bpr) * 256 + (int)threadIdx.x) * 4;
+    if (row >= M || col >= N) return;
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f), b = a;
+    for (int z = 0; z < ksplit; ++z) {  // (the same fixed order of the sum as the one-column kernel)
+        const float4 p = *reinterpret_cast<const float4*>(part + ((int64_t)z * M + row) * N + col);
+        a.x += p.x, a.y += p.y, a.z += p.z, a.w += p.w;
+        if (epi == PARROT_EPI_SWIGLU) {
+            const float4 q = *reinterpret_cast<const float4*>(part2 + ((int64_t)z * M + row) * N + col);
+            b.x += q.x, b.y += q.y, b.z += q.z, b.w += q.w;
+        }
+    }
+    const float av[4] = {a.x, a.y, a.z, a.w}, bv[4] = {b.x, b.y, b.z, b.w};
+    bf16_t o[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        if (epi == PARROT_EPI_SWIGLU)
+            o[c] = f2bf(bf2f(f2bf(silu(rbf(av[c])))) * rbf(bv[c]));
+        else
+            o[c] = apply_epilogue(epi, av[c], 0.f, bias, residual ? residual + (int64_t)row * ldr : nullptr, col + c);
+    }
+    *reinterpret_cast<uint2*>(out + (int64_t)row * ldo + col) = make_uint2((uint32_t)o[0] | ((uint32_t)o[1] << 16), (uint32_t)o[2] | ((uint32_t)o[3] << 16));
+}
+
+int launch_splitk_epilogue(const float* part, const float* part2, int ksplit, int M, int N, const bf16_t* bias, const bf16_t* residual,
+                           int ldr, bf16_t* out, int ldo, int epi, hipStream_t st) {
+    const bool vec = N % 4 == 0 && ldo % 4 == 0 && (reinterpret_cast<uintptr_t>(out) & 7u) == 0 && aligned16(part) && (!part2 || aligned16(part2));
+    if (vec)
+        return launch(K_GEMM_SPLITK, gemm_splitk_epilogue4_kernel, dim3((unsigned)((int64_t)M * ((N + 1023) / 1024))), dim3(256), 0, st, part, part2,
+                      ksplit, M, N, bias, residual, ldr, out, ldo, epi);
+    return launch(K_GEMM_SPLITK, gemm_splitk_epilogue_kernel, dim3((unsigned)((int64_t)M * ((N + 255) / 256))), dim3(256), 0, st, part, part2, ksplit,
+                  M, N, bias, residual, ldr, out, ldo, epi);
+}
+
 // 128 x 128 tiles only when they alone give the chip >= 2 workgroups per CU; otherwise 64 x 64 (4x the workgroups)
 static bool gemm_big_tiles(int M, int N) {
     const int env = tune_env("PARROT_GEMM_BIG_MIN", 512);  // PARROT_GEMM_BIG_MIN: minimum number of 128 x 128 tiles for the big-tile kernel (experiment hook)
@@ -344,8 +383,7 @@ static int gemm_launch(int kid, const void* Wp, const void* W2p, const void* x, 
 #undef PARROT_GEMM_GO2
     if (rc != PARROT_OK || ksplit == 1) return rc;
     const int64_t n = (int64_t)M * N;
-    return launch(K_GEMM_SPLITK, gemm_splitk_epilogue_kernel, dim3((unsigned)((int64_t)M * ((N + 255) / 256))), dim3(256), 0, st, (const float*)part,
-                  (const float*)part2, ksplit, M, N, (const bf16_t*)bias, (const bf16_t*)residual, ldr, (bf16_t*)out, ldo, epilogue);
+    return launch_splitk_epilogue((const float*)part, (const float*)part2, ksplit, M, N, (const bf16_t*)bias, (const bf16_t*)residual, ldr, (bf16_t*)out, ldo, epilogue, st);
 }
 
 // second-generation bf16 kernel (gemm2.hip)
@@ -412,9 +450,7 @@ int parrot_bf16_gemm(const void* W, const void* W2, const void* x, int ldx, int 
         rc = gemm2_launch(W, x, ldx, M, bias, residual, ldr, out, ldo, N, K, epilogue, (float*)workspace, (hipStream_t)stream, &ks);
         if (rc != PARROT_OK || ks == 1) return rc;
         const int64_t n = (int64_t)M * N;
-        return launch(K_GEMM_SPLITK, gemm_splitk_epilogue_kernel, dim3((unsigned)((int64_t)M * ((N + 255) / 256))), dim3(256), 0, (hipStream_t)stream,
-                      (const float*)workspace, (const float*)nullptr, ks, M, N, (const bf16_t*)bias, (const bf16_t*)residual, ldr,
-                      (bf16_t*)out, ldo, epilogue);
+        return launch_splitk_epilogue((const float*)workspace, (const float*)nullptr, ks, M, N, (const bf16_t*)bias, (const bf16_t*)residual, ldr, (bf16_t*)out, ldo, epilogue, (hipStream_t)stream);
     }
     W4Plan plan = {};
     return gemm_launch<false>(K_BF16_GEMM, W, W2, x, ldx, M, bias, residual, ldr, out, ldo, N, K, epilogue, nullptr, (float*)workspace,
@@ -442,8 +478,7 @@ int parrot_w4_gemm(const void* packed, const void* packed2, const void* x, int l
                              &part, &part2, nullptr);
         if (rc != PARROT_OK || ks == 1) return rc;
         const int64_t mn = (int64_t)M * N;
-        return launch(K_GEMM_SPLITK, gemm_splitk_epilogue_kernel, dim3((unsigned)((int64_t)M * ((N + 255) / 256))), dim3(256), 0, st, (const float*)part,
-                      (const float*)part2, ks, M, N, (const bf16_t*)bias, (const bf16_t*)residual, ldr, (bf16_t*)out, ldo, epilogue);
+        return launch_splitk_epilogue((const float*)part, (const float*)part2, ks, M, N, (const bf16_t*)bias, (const bf16_t*)residual, ldr, (bf16_t*)out, ldo, epilogue, st);
     }
     const int G = plan.Gs * 32;
     const int64_t n = (int64_t)M * plan.ngroups;
@@ -479,8 +514,7 @@ int parrot_w4c_gemm(const void* packed, const void* packed2, const void* code16_
                          &part2, code16_bf16);
     if (rc != PARROT_OK || ks == 1) return rc;
     const int64_t mn = (int64_t)M * N;
-    return launch(K_GEMM_SPLITK, gemm_splitk_epilogue_kernel, dim3((unsigned)((int64_t)M * ((N + 255) / 256))), dim3(256), 0, st, (const float*)part,
-                  (const float*)part2, ks, M, N, (const bf16_t*)bias, (const bf16_t*)residual, ldr, (bf16_t*)out, ldo, epilogue);
+    return launch_splitk_epilogue((const float*)part, (const float*)part2, ks, M, N, (const bf16_t*)bias, (const bf16_t*)residual, ldr, (bf16_t*)out, ldo, epilogue, st);
 }
 
 }  // extern "C"

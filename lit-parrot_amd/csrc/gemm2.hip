@@ -176,6 +176,16 @@ gemm2_kernel(const bf16_t* __restrict__ A, int lda, int M, const bf16_t* __restr
     }
 
     // C layout of the 32x32 MFMA: column = lane & 31, row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5)
+    if (SPLIT && m0 + TM <= M && n0 + G2N <= N) {  // interior tile (wave-uniform): 64 stores off one base, no per-element bounds
+        float* d0 = part + ((int64_t)zsplit * M + m0 + wm * 64 + 4 * lh) * N + n0 + wn * 64 + lr;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) d0[(int64_t)(i * 32 + (r & 3) + 8 * (r >> 2)) * N + j * 32] = acc[i][j][r];
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -275,21 +285,29 @@ int gemm2_launch(const void* W, const void* x, int ldx, int M, const void* bias,
 //     {scale, zero} words of a group reach LDS by 4-byte LDS-DMA one group ahead (no VGPR-destination load in the loop: the
 //     compiler would answer one with vmcnt(0) and drain the ring).
 // Takes group sizes that are multiples of 64 (whole K-steps per group); everything else stays on gemm.hip.
+// 16 lanes per (row, group): lane c takes the 16-byte pieces c, c + 16, ... of the group (256 contiguous bytes per 16 lanes for
+// groups of 128), then a 16-lane butterfly; the first version's one thread per (row, group) read 64 different lines per wave
+// instruction and took 4.4 us on 128 x 4096 activations.
 __global__ void __launch_bounds__(256)
 gemm2_xsum_kernel(const bf16_t* __restrict__ x, int ldx, int M, int Mpad, int K, int G, int ngroups, float* __restrict__ xsT) {
-    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= (int64_t)Mpad * ngroups) return;
+    const int64_t t = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 4;
+    const int c0 = threadIdx.x & 15;
+    if (t >= (int64_t)Mpad * ngroups) return;  // (whole 16-lane groups leave together)
     const int g = (int)(t / Mpad), m = (int)(t % Mpad);
     float s = 0.f;
     if (m < M) {
         const int k0 = g * G, k1 = min(K, k0 + G);
         const uint4* p = reinterpret_cast<const uint4*>(x + (int64_t)m * ldx + k0);
-        for (int c = 0; c < (k1 - k0) / 8; ++c) {
+        for (int c = c0; c < (k1 - k0) / 8; c += 16) {
             const uint4 v = p[c];
             s += (bflo(v.x) + bfhi(v.x)) + (bflo(v.y) + bfhi(v.y)) + (bflo(v.z) + bfhi(v.z)) + (bflo(v.w) + bfhi(v.w));
         }
     }
-    xsT[t] = s;
+    s += __shfl_xor(s, 1);
+    s += __shfl_xor(s, 2);
+    s += __shfl_xor(s, 4);
+    s += __shfl_xor(s, 8);
+    if (c0 == 0) xsT[t] = s;
 }
 
 // LDS-DMA issued from inline asm.  With the builtin, hipcc put an s_waitcnt vmcnt(0) in front of the first fragment read of every
@@ -636,17 +654,27 @@ gemm2_w4_kernel(const bf16_t* __restrict__ A, int lda, int M, const uint4* __res
         }
         if constexpr (SPLIT) {
             float* dst = (pass ? part2 : part) + (int64_t)zsplit * M * N;
+            if (m0 + G2M <= M && n0 + TN <= N) {  // interior tile (wave-uniform): 64 stores off one base, no per-element bounds
+                float* d0 = dst + (int64_t)(m0 + wm * 64 + 4 * lh) * N + n0;
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+                for (int i = 0; i < 2; ++i)
 #pragma unroll
-                for (int j = 0; j < 2; ++j) {
-                    const int col = n0 + c_row[j];
+                    for (int j = 0; j < 2; ++j)
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        const int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                        if (row < M && col < N) dst[(int64_t)row * N + col] = total[i][j][r];
+                        for (int r = 0; r < 16; ++r) d0[(int64_t)(i * 32 + (r & 3) + 8 * (r >> 2)) * N + c_row[j]] = total[i][j][r];
+            } else {
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        const int col = n0 + c_row[j];
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                            if (row < M && col < N) dst[(int64_t)row * N + col] = total[i][j][r];
+                        }
                     }
-                }
+            }
         } else if (SWI && pass == 0) {
 #pragma unroll
             for (int i = 0; i < 2; ++i)
@@ -724,7 +752,7 @@ int gemm2_w4_launch(const void* Wq, const void* Wq2, const void* x, int ldx, int
     const int64_t nxs = code ? 0 : (int64_t)Mpad * plan.ngroups;  // codebook weights need no activation sums
     int rc = PARROT_OK;
     if (!code)
-        rc = launch(K_GEMM_XSUM, gemm2_xsum_kernel, dim3((unsigned)((nxs + 255) / 256)), dim3(256), 0, st, (const bf16_t*)x, ldx, M, Mpad, K,
+        rc = launch(K_GEMM_XSUM, gemm2_xsum_kernel, dim3((unsigned)((nxs * 16 + 255) / 256)), dim3(256), 0, st, (const bf16_t*)x, ldx, M, Mpad, K,
                     plan.Gs * 32, plan.ngroups, workspace);
     if (rc != PARROT_OK) return rc;
     const int ks = gemm2_w4_ksplit(M, N, K, plan);
