@@ -33,6 +33,9 @@ constexpr int G2M = 128, G2N = 128, G2K = 64;
 #endif
 constexpr bool G2_PRIO = PARROT_G2_PRIO;  // raise the wave priority over the MFMA cluster (build-time A/B)
 constexpr int G2_TILE16 = 128 * 8;  // 16-byte units of one operand tile (128 rows x 128 B)
+#ifndef G2_B_AUX
+#define G2_B_AUX 0  // cache policy bits of the weight tiles' LDS-DMA (2 = nt: A/B in profiles/r03a)
+#endif
 
 // Workgroup id -> (m tile, n tile, K split).  Workgroups are dealt to the 8 XCDs round-robin and each XCD has its own L2, so
 // the tiles that share operands must (a) sit on one XCD and (b) run at the same time: XCD x owns a contiguous range of
@@ -116,7 +119,7 @@ gemm2_kernel(const bf16_t* __restrict__ A, int lda, int M, const bf16_t* __restr
 #pragma unroll
         for (int i = 0; i < B_LOADS; ++i)
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(b_src[i] + (int64_t)kt * G2K),
-                                             (__attribute__((address_space(3))) void*)&st[A16 + (wave * B_LOADS + i) * 64], 16, 0, 0);
+                                             (__attribute__((address_space(3))) void*)&st[A16 + (wave * B_LOADS + i) * 64], 16, 0, G2_B_AUX);
     };
 
     f32x16_t acc[2][2];
