@@ -15,6 +15,8 @@
 // P in fp32): results agree with the multi-row decode path to bf16 rounding.
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "parrot_common.h"
 
 namespace parrot {
@@ -159,7 +161,7 @@ attn_prefill_kernel(const bf16_t* __restrict__ q, int ldq, int M, const int32_t*
 // (32 keys = 64 B) to 72 B (a ds_read_b64 half-wave reads 32 dims: 18 * dim mod 64 are 32 distinct even banks).
 // The next block travels global -> registers while the current one is multiplied, and is written behind a barrier.
 template <int HS>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))
 attn_prefill_lds_kernel(const bf16_t* __restrict__ q, int ldq, int M, const int32_t* __restrict__ pos_ptr, const bf16_t* __restrict__ k_cache,
                         const bf16_t* __restrict__ vT, int n_groups, int q_per_kv, int S, int Spad, bf16_t* __restrict__ y, int ldy) {
     // An LDS image holds TWO key blocks (64 keys): one pair of barriers and one exposed global -> LDS hand-over per 64 keys
@@ -202,95 +204,119 @@ attn_prefill_lds_kernel(const bf16_t* __restrict__ q, int ldq, int M, const int3
     const int n_img = (n_kb + 1) / 2;                                               // LDS images of two key blocks
     // staging assignment: K piece p of thread t: row (t * KPT + p) / (HS / 8), 16-byte column (t * KPT + p) % (HS / 8);
     //                     V^T piece: dim (t * VPT + p) / 8, 16-byte column (t * VPT + p) % 8 (8 keys)
-    uint4 rk[KPT], rv[VPT];
+    // (named registers: as arrays filled in one lambda and read in another the staged pieces went through scratch memory)
+    uint4 rk0, rk1, rk2 = make_uint4(0, 0, 0, 0), rk3 = rk2, rv0, rv1, rv2 = rk2, rv3 = rk2;
+    auto kload = [&](int im, int p) {
+        const int idx = tid * KPT + p, row = idx / (HS / 8), c = idx % (HS / 8);
+        return *reinterpret_cast<const uint4*>(kc + (int64_t)min(im * 64 + row, S - 1) * HS + c * 8);
+    };
+    auto vload = [&](int im, int p) {
+        const int idx = tid * VPT + p, dim = idx / 8, c = idx % 8;
+        return *reinterpret_cast<const uint4*>(vg + (int64_t)dim * Spad + im * 64 + c * 8);  // (Spad is a multiple of 64)
+    };
+    auto kstore = [&](int p, const uint4 v) {
+        const int idx = tid * KPT + p, row = idx / (HS / 8), c = idx % (HS / 8);
+        *reinterpret_cast<uint4*>(&Ks[row * KLD + c * 8]) = v;
+    };
+    auto vstore = [&](int p, const uint4 v) {
+        const int idx = tid * VPT + p, dim = idx / 8, c = idx % 8;
+        uint2* dst = reinterpret_cast<uint2*>(&Vs[dim * VLD + c * 8]);  // 136-byte rows: 8-byte aligned
+        dst[0] = make_uint2(v.x, v.y);
+        dst[1] = make_uint2(v.z, v.w);
+    };
     auto fetch = [&](int im) {
-#pragma unroll
-        for (int p = 0; p < KPT; ++p) {
-            const int idx = tid * KPT + p, row = idx / (HS / 8), c = idx % (HS / 8);
-            rk[p] = *reinterpret_cast<const uint4*>(kc + (int64_t)min(im * 64 + row, S - 1) * HS + c * 8);
-        }
-#pragma unroll
-        for (int p = 0; p < VPT; ++p) {
-            const int idx = tid * VPT + p, dim = idx / 8, c = idx % 8;
-            rv[p] = *reinterpret_cast<const uint4*>(vg + (int64_t)dim * Spad + im * 64 + c * 8);  // (Spad is a multiple of 64)
+        rk0 = kload(im, 0), rk1 = kload(im, 1);
+        rv0 = vload(im, 0), rv1 = vload(im, 1);
+        if constexpr (KPT == 4) {
+            rk2 = kload(im, 2), rk3 = kload(im, 3);
+            rv2 = vload(im, 2), rv3 = vload(im, 3);
         }
     };
     auto stage = [&]() {
-#pragma unroll
-        for (int p = 0; p < KPT; ++p) {
-            const int idx = tid * KPT + p, row = idx / (HS / 8), c = idx % (HS / 8);
-            *reinterpret_cast<uint4*>(&Ks[row * KLD + c * 8]) = rk[p];
-        }
-#pragma unroll
-        for (int p = 0; p < VPT; ++p) {
-            const int idx = tid * VPT + p, dim = idx / 8, c = idx % 8;
-            uint2* dst = reinterpret_cast<uint2*>(&Vs[dim * VLD + c * 8]);  // 136-byte rows: 8-byte aligned
-            dst[0] = make_uint2(rv[p].x, rv[p].y);
-            dst[1] = make_uint2(rv[p].z, rv[p].w);
+        kstore(0, rk0), kstore(1, rk1);
+        vstore(0, rv0), vstore(1, rv1);
+        if constexpr (KPT == 4) {
+            kstore(2, rk2), kstore(3, rk3);
+            vstore(2, rv2), vstore(3, rv3);
         }
     };
     fetch(0);
     stage();
     __syncthreads();
-    for (int im = 0; im < n_img; ++im) {
-        if (im + 1 < n_img) fetch(im + 1);
+    // One softmax step over NB key blocks of the image (NB = 2: both; 1: only the first - the second lies past this wave's diagonal,
+    // and past the zero-filled part of V^T).  Two blocks per step: their S accumulators are independent (no MFMA waits on the one in
+    // front of it), one rescale of the running output per 64 keys, 16 P.V MFMAs in four independent chains.
+    auto process = [&](auto nb_tag, int kb0) {
+        constexpr int NB = decltype(nb_tag)::value;
+        f32x16_t sacc[NB];
 #pragma unroll
-        for (int sub = 0; sub < 2; ++sub) {
-            const int kb = 2 * im + sub;
-            if (kb < my_kb) {
-                f32x16_t sacc;
+        for (int b = 0; b < NB; ++b)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) sacc[r] = 0.f;
+            for (int r = 0; r < 16; ++r) sacc[b][r] = 0.f;
 #pragma unroll
-                for (int ks = 0; ks < KS; ++ks) {
-                    const bf16x8_t kf = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(&Ks[(sub * 32 + lr) * KLD + ks * 16 + lh * 8]));
-                    sacc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], sacc, 0, 0, 0);
-                }
-                float mx = -INFINITY;
+        for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int key = kb * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-                    const float sv = key <= qpos ? sacc[r] * scale : -INFINITY;
-                    sacc[r] = sv;
-                    mx = fmaxf(mx, sv);
-                }
-                mx = fmaxf(mx, __shfl_xor(mx, 32));
-                const float m_new = fmaxf(m_run, mx);
-                const float alpha = __expf(m_run - m_new);
-                float lsum = 0.f, p[16];
+            for (int b = 0; b < NB; ++b) {
+                const bf16x8_t kf = __builtin_bit_cast(bf16x8_t, *reinterpret_cast<const uint4*>(&Ks[(b * 32 + lr) * KLD + ks * 16 + lh * 8]));
+                sacc[b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[ks], sacc[b], 0, 0, 0);
+            }
+        float mx = -INFINITY;
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    p[r] = __expf(sacc[r] - m_new);
-                    lsum += p[r];
-                }
-                lsum += __shfl_xor(lsum, 32);
-                l_run = l_run * alpha + lsum;
-                m_run = m_new;
+        for (int b = 0; b < NB; ++b)
 #pragma unroll
-                for (int dt = 0; dt < DT; ++dt)
+            for (int r = 0; r < 16; ++r) {
+                const int key = (kb0 + b) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                const float sv = key <= qpos ? sacc[b][r] * scale : -INFINITY;
+                sacc[b][r] = sv;
+                mx = fmaxf(mx, sv);
+            }
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        const float m_new = fmaxf(m_run, mx);
+        const float alpha = __expf(m_run - m_new);
+        float lsum = 0.f, p[NB][16];
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
-                bf16x8_t pf[2];
+        for (int b = 0; b < NB; ++b)
 #pragma unroll
-                for (int ks = 0; ks < 2; ++ks) {
-                    uint32_t w[4];
+            for (int r = 0; r < 16; ++r) {
+                p[b][r] = __expf(sacc[b][r] - m_new);
+                lsum += p[b][r];
+            }
+        lsum += __shfl_xor(lsum, 32);
+        l_run = l_run * alpha + lsum;
+        m_run = m_new;
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) w[i] = (uint32_t)f2bf(p[8 * ks + 2 * i]) | ((uint32_t)f2bf(p[8 * ks + 2 * i + 1]) << 16);
-                    pf[ks] = __builtin_bit_cast(bf16x8_t, make_uint4(w[0], w[1], w[2], w[3]));
-                }
+        for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[dt][r] *= alpha;
+        bf16x8_t pf[NB][2];
+#pragma unroll
+        for (int b = 0; b < NB; ++b)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                uint32_t w[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) w[i] = (uint32_t)f2bf(p[b][8 * ks + 2 * i]) | ((uint32_t)f2bf(p[b][8 * ks + 2 * i + 1]) << 16);
+                pf[b][ks] = __builtin_bit_cast(bf16x8_t, make_uint4(w[0], w[1], w[2], w[3]));
+            }
+#pragma unroll
+        for (int b = 0; b < NB; ++b)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
                 for (int dt = 0; dt < DT; ++dt) {
-                    const bf16_t* vp = &Vs[(dt * 32 + lr) * VLD + sub * 32 + 4 * lh];
-#pragma unroll
-                    for (int ks = 0; ks < 2; ++ks) {
-                        const uint2 v0 = *reinterpret_cast<const uint2*>(vp + 16 * ks);
-                        const uint2 v1 = *reinterpret_cast<const uint2*>(vp + 16 * ks + 8);
-                        const bf16x8_t vf = __builtin_bit_cast(bf16x8_t, make_uint4(v0.x, v0.y, v1.x, v1.y));
-                        o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[ks], o[dt], 0, 0, 0);
-                    }
+                    const bf16_t* vp = &Vs[(dt * 32 + lr) * VLD + b * 32 + 16 * ks + 4 * lh];
+                    const uint2 v0 = *reinterpret_cast<const uint2*>(vp);
+                    const uint2 v1 = *reinterpret_cast<const uint2*>(vp + 8);
+                    const bf16x8_t vf = __builtin_bit_cast(bf16x8_t, make_uint4(v0.x, v0.y, v1.x, v1.y));
+                    o[dt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[b][ks], o[dt], 0, 0, 0);
                 }
-            }
-        }
+    };
+    for (int im = 0; im < n_img; ++im) {
+        if (im + 1 < n_img) fetch(im + 1);
+        if (2 * im + 1 < my_kb)
+            process(std::integral_constant<int, 2>{}, 2 * im);
+        else if (2 * im < my_kb)
+            process(std::integral_constant<int, 1>{}, 2 * im);
         __syncthreads();  // everybody is done with this LDS image
         if (im + 1 < n_img) {
             stage();
