@@ -843,14 +843,17 @@ __global__ void __launch_bounds__(256)
 w8_sub_gather_kernel(const float* __restrict__ xout, const int8_t* __restrict__ CB, const float* __restrict__ SCB, const int32_t* __restrict__ nout,
                      const int32_t* __restrict__ oidx, __half* __restrict__ subA, __half* __restrict__ subB, int M, int N, int K) {
     const int nu = nout[0], nu16 = (nu + 15) & ~15;
-    const int r = blockIdx.x;  // rows 0 .. M-1: A;  M .. M+N-1: weight rows.  One workgroup per row walks the list
-    const float scb = r >= M ? SCB[r - M] : 0.f;
-    for (int j = threadIdx.x; j < nu16; j += 256) {
-        const int k = j < nu ? oidx[j] : -1;
-        if (r < M)
-            subA[(int64_t)r * K + j] = __float2half(k >= 0 ? xout[(int64_t)r * K + k] : 0.f);
-        else
-            subB[(int64_t)(r - M) * K + j] = __float2half(k >= 0 ? rhalf(__fdiv_rn(__fmul_rn((float)CB[(int64_t)(r - M) * K + k], scb), 127.0f)) : 0.f);
+    if (nu == 0) return;  // (a call without outlier columns - every synthetic-weight prompt - must cost a launch, not a grid of M + N workgroups)
+    // rows 0 .. M-1: A;  M .. M+N-1: weight rows.  A workgroup walks the list for its rows (grid-stride: at most 2048 workgroups)
+    for (int r = blockIdx.x; r < M + N; r += gridDim.x) {
+        const float scb = r >= M ? SCB[r - M] : 0.f;
+        for (int j = threadIdx.x; j < nu16; j += 256) {
+            const int k = j < nu ? oidx[j] : -1;
+            if (r < M)
+                subA[(int64_t)r * K + j] = __float2half(k >= 0 ? xout[(int64_t)r * K + k] : 0.f);
+            else
+                subB[(int64_t)(r - M) * K + j] = __float2half(k >= 0 ? rhalf(__fdiv_rn(__fmul_rn((float)CB[(int64_t)(r - M) * K + k], scb), 127.0f)) : 0.f);
+        }
     }
 }
 
@@ -1049,7 +1052,7 @@ int parrot_w8_gemm(const void* CB, const void* SCB, const void* xq, const void* 
     __half* subA = reinterpret_cast<__half*>((reinterpret_cast<uintptr_t>(O1 + (int64_t)M * N * (swi ? 2 : 1)) + 15) & ~(uintptr_t)15);
     __half* subB = subA + (int64_t)M * K;
     const int Ntot = swi ? 2 * N : N;
-    rc = launch(K_W8_OUTLIER, w8_sub_gather_kernel, dim3((unsigned)(M + Ntot)), dim3(256), 0, st, (const float*)xout,
+    rc = launch(K_W8_OUTLIER, w8_sub_gather_kernel, dim3((unsigned)(M + Ntot < 2048 ? M + Ntot : 2048)), dim3(256), 0, st, (const float*)xout,
                 (const int8_t*)CB, (const float*)SCB, (const int32_t*)nout, (const int32_t*)oidx, subA, subB, M, Ntot, K);
     if (rc != PARROT_OK) return rc;
     const dim3 ogrid((unsigned)((N + 63) / 64), (unsigned)((M + 63) / 64));
