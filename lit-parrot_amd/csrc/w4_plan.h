@@ -31,7 +31,10 @@ inline int w4_make_plan(int N, int K, int group, W4Plan* p) {
     PARROT_UNSUPPORTED(group % 32 == 0, "w4: group size %d must be a multiple of 32", group);
     const int nslices = K / 32;
     const int Gs = group / 32;
-    const int unit = Gs <= 64 ? Gs : 1;  // slab boundaries fall on group starts when a group fits a slab
+    // slab boundaries fall on group starts when a group fits a slab; otherwise (per-channel scales, huge groups) on EVEN slices,
+    // i.e. on the 64-deep K-steps of the prompt GEMM (gemm2_w4_takes: a slab that starts on an odd slice sent Falcon-7B's
+    // per-channel gptq.int4 prompts to the first-generation kernel - 45.8 ms for 128 tokens)
+    const int unit = Gs <= 64 ? Gs : (nslices % 2 == 0 ? 2 : 1);
     const int units = (nslices + unit - 1) / unit;
     int nslabs = (nslices + 63) / 64;
     while (nslabs <= kMaxSlabs && ((units + nslabs - 1) / nslabs) * unit > 64) ++nslabs;
