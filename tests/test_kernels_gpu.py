@@ -186,7 +186,8 @@ def test_w4_module_forward_shape_and_bad_inputs():
 
 
 # ------------------------------------------------------------------------------------------------ MFMA prefill GEMMs
-@pytest.mark.parametrize("N,K,group", [(96, 512, 128), (256, 4096, 128), (200, 352, 128), (128, 256, -1), (64, 256, 32), (130, 11008, 128)])
+@pytest.mark.parametrize("N,K,group", [(96, 512, 128), (256, 4096, 128), (200, 352, 128), (128, 256, -1), (64, 256, 32), (130, 11008, 128),
+                                       (72, 4544, -1)])  # (Falcon-7B's width, per-channel: three slabs, whose starts must be even slices)
 @pytest.mark.parametrize("M", [9, 37, 128, 200])
 def test_w4_gemm_matches_oracle_and_the_gemv(N, K, group, M):
     qw, s, z, tc, Wd = make_w4(N, K, group, 30)
