@@ -385,7 +385,17 @@ gemm2_w4_kernel(const bf16_t* __restrict__ A, int lda, int M, const uint4* __res
     __shared__ __attribute__((aligned(4096))) uint4 smem_all[CB16 + W4_NBUF * W4_STAGE16 + 2 * W4_META16];
     uint4* const smem = smem_all + CB16;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave / WN, wn = wave % WN;
+    // wave layout: WN columns of 64 x 64 waves (two row blocks x two column blocks each), or - the 128 x 128 tile -
+    // four waves side by side, each ALL 128 rows x 32 columns: every wave expands only its own 32 columns of weights (half
+    // the expansion VALU per wave and step) and reads all four row blocks of A instead (twice the A fragment reads)
+#ifndef G2W_L22  // (-DG2W_L22: the 2 x 2 layout on the 128 x 128 tile too - A/B in profiles/r03a: 1 x 4 is 3 - 5 % faster at 512 rows, equal at 128)
+    constexpr bool L14 = (WN == 2);
+#else
+    constexpr bool L14 = false;
+#endif
+    constexpr int IM = L14 ? 4 : 2, JN = L14 ? 1 : 2;
+    const int wm = L14 ? 0 : wave / WN, wn = L14 ? wave : wave % WN;
+    const int rowb = L14 ? 0 : wm * 64, colb = L14 ? wn * 32 : wn * 64;  // first tile row / column of the wave
     if constexpr (CB) {  // (visible after the barrier that opens the first pass)
         if (((uint32_t)(uintptr_t)smem_all & 0xFFFFu) != 0) __builtin_trap();  // the lookups write the nibble into byte 1 of an address based at 0
         for (int e = wave; e < 16; e += NWAVES) reinterpret_cast<uint32_t*>(smem_all)[e * 64 + lane] = code[e];
@@ -431,17 +441,18 @@ gemm2_w4_kernel(const bf16_t* __restrict__ A, int lda, int M, const uint4* __res
     const int64_t ml_rec = (int64_t)min(n0 + max(wave - 2, 0) * 64 + lane, N - 1) * plan.row16;
     const float* xs_src = xsT + m0 + (wave & 1) * 64 + lane;
 
-    int a_row[2], c_row[2], b_unit[2];
+    int a_row[IM], c_row[JN], b_unit[JN];
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        a_row[i] = wm * 64 + i * 32 + lr;
-        c_row[i] = wn * 64 + i * 32 + lr;
-        b_unit[i] = c_row[i] * 2 + (lh ^ ((c_row[i] >> 3) & 1));
+    for (int i = 0; i < IM; ++i) a_row[i] = rowb + i * 32 + lr;
+#pragma unroll
+    for (int j = 0; j < JN; ++j) {
+        c_row[j] = colb + j * 32 + lr;
+        b_unit[j] = c_row[j] * 2 + (lh ^ ((c_row[j] >> 3) & 1));
     }
     uint4* const meta = smem + W4_NBUF * W4_STAGE16;
 
-    f32x16_t total[2][2];
-    uint32_t gate[SWI && !SPLIT ? 2 : 1][SWI && !SPLIT ? 2 : 1][8];
+    f32x16_t total[IM][JN];
+    uint32_t gate[SWI && !SPLIT ? IM : 1][SWI && !SPLIT ? JN : 1][8];
     static_assert(!(SPLIT && SWI), "a split SwiGLU pair runs the plain split kernel with the pass in the grid");
     // The K loop is bound by instruction ISSUE, not by the matrix pipe (16 MFMAs per wave and step are 512 pipe cycles; the first
     // version of this loop issued 512 instructions per step - 203 scalar ones for slab walks, 64-bit addresses and M0 saves,
@@ -465,11 +476,11 @@ gemm2_w4_kernel(const bf16_t* __restrict__ A, int lda, int M, const uint4* __res
     asm("" : "+v"(magic));
     for (int pass = pass_begin; pass < pass_end; ++pass) {
         const uint4* Wp = pass ? Wq2 : Wq;
-        f32x16_t acc[2][2];
+        f32x16_t acc[IM][JN];
 #pragma unroll
-        for (int i = 0; i < 2; ++i)
+        for (int i = 0; i < IM; ++i)
 #pragma unroll
-            for (int j = 0; j < 2; ++j)
+            for (int j = 0; j < JN; ++j)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[i][j][r] = total[i][j][r] = 0.f;
         // ---- issue cursors (wave-uniform): the next K-step to issue, its slab, the byte positions of its A columns / B slices
@@ -569,15 +580,20 @@ gemm2_w4_kernel(const bf16_t* __restrict__ A, int lda, int M, const uint4* __res
             const uint4* sb = sa + G2_TILE16;
             // this lane's 2 x 4 dwords of packed weights: k-block lh * 4 + ks of the step goes to MFMA ks (any assignment of the
             // step's eight 8-k blocks to (MFMA, lane half) is valid as long as A uses the same one)
-            const uint4 bq0 = sb[b_unit[0]], bq1 = sb[b_unit[1]];
-            const uint32_t bw[2][4] = {{bq0.x, bq0.y, bq0.z, bq0.w}, {bq1.x, bq1.y, bq1.z, bq1.w}};
+            uint32_t bw[JN][4];
+#pragma unroll
+            for (int j = 0; j < JN; ++j) {
+                const uint4 bq = sb[b_unit[j]];
+                bw[j][0] = bq.x, bw[j][1] = bq.y, bw[j][2] = bq.z, bw[j][3] = bq.w;
+            }
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
                 const int slot = lh * 4 + ks;
-                bf16x8_t af[2], bfr[2];
+                bf16x8_t af[IM], bfr[JN];
 #pragma unroll
-                for (int i = 0; i < 2; ++i) {
-                    af[i] = __builtin_bit_cast(bf16x8_t, sa[a_row[i] * 8 + (slot ^ ((a_row[i] >> 1) & 7))]);
+                for (int i = 0; i < IM; ++i) af[i] = __builtin_bit_cast(bf16x8_t, sa[a_row[i] * 8 + (slot ^ ((a_row[i] >> 1) & 7))]);
+#pragma unroll
+                for (int i = 0; i < JN; ++i) {
                     uint32_t o[4];
                     if constexpr (CB) {
                         w4c_dword_lookup(bw[i][ks], cb_addr, o);
@@ -588,9 +604,9 @@ gemm2_w4_kernel(const bf16_t* __restrict__ A, int lda, int M, const uint4* __res
                     bfr[i] = __builtin_bit_cast(bf16x8_t, make_uint4(o[0], o[1], o[2], o[3]));
                 }
 #pragma unroll
-                for (int i = 0; i < 2; ++i)
+                for (int i = 0; i < IM; ++i)
 #pragma unroll
-                    for (int j = 0; j < 2; ++j) {
+                    for (int j = 0; j < JN; ++j) {
 #ifdef G2W_STUB_NOMFMA
                         if (true) {
                             asm volatile("" ::"v"(af[i]), "v"(bfr[j]));
@@ -620,19 +636,19 @@ gemm2_w4_kernel(const bf16_t* __restrict__ A, int lda, int M, const uint4* __res
                 const uint4* mb = meta + (g & 1) * W4_META16;
                 const float* xs_l = reinterpret_cast<const float*>(mb);
                 const uint32_t* mt_l = reinterpret_cast<const uint32_t*>(mb + 32);
-                float4 xs4[2][4];
+                float4 xs4[IM][4];
                 if constexpr (!CB) {
 #pragma unroll
-                    for (int i = 0; i < 2; ++i)
+                    for (int i = 0; i < IM; ++i)
 #pragma unroll
-                        for (int q = 0; q < 4; ++q) xs4[i][q] = *reinterpret_cast<const float4*>(xs_l + wm * 64 + i * 32 + 8 * q + 4 * lh);
+                        for (int q = 0; q < 4; ++q) xs4[i][q] = *reinterpret_cast<const float4*>(xs_l + rowb + i * 32 + 8 * q + 4 * lh);
                 }
 #pragma unroll
-                for (int j = 0; j < 2; ++j) {
+                for (int j = 0; j < JN; ++j) {
                     const uint32_t mt = mt_l[c_row[j]];
                     const float sc = CB ? __uint_as_float(mt) : bflo(mt), zz = CB ? 0.f : 128.0f + bfhi(mt);
 #pragma unroll
-                    for (int i = 0; i < 2; ++i)
+                    for (int i = 0; i < IM; ++i)
 #pragma unroll
                         for (int r = 0; r < 16; ++r) {
                             if constexpr (CB) {
@@ -650,39 +666,39 @@ gemm2_w4_kernel(const bf16_t* __restrict__ A, int lda, int M, const uint4* __res
             }
 #else
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+            for (int i = 0; i < IM; ++i)
 #pragma unroll
-                for (int j = 0; j < 2; ++j) total[i][j] += acc[i][j];
+                for (int j = 0; j < JN; ++j) total[i][j] += acc[i][j];
 #endif
         }
         if constexpr (SPLIT) {
             float* dst = (pass ? part2 : part) + (int64_t)zsplit * M * N;
             if (m0 + G2M <= M && n0 + TN <= N) {  // interior tile (wave-uniform): 64 stores off one base, no per-element bounds
-                float* d0 = dst + (int64_t)(m0 + wm * 64 + 4 * lh) * N + n0;
+                float* d0 = dst + (int64_t)(m0 + rowb + 4 * lh) * N + n0;
 #pragma unroll
-                for (int i = 0; i < 2; ++i)
+                for (int i = 0; i < IM; ++i)
 #pragma unroll
-                    for (int j = 0; j < 2; ++j)
+                    for (int j = 0; j < JN; ++j)
 #pragma unroll
                         for (int r = 0; r < 16; ++r) d0[(int64_t)(i * 32 + (r & 3) + 8 * (r >> 2)) * N + c_row[j]] = total[i][j][r];
             } else {
 #pragma unroll
-                for (int i = 0; i < 2; ++i)
+                for (int i = 0; i < IM; ++i)
 #pragma unroll
-                    for (int j = 0; j < 2; ++j) {
+                    for (int j = 0; j < JN; ++j) {
                         const int col = n0 + c_row[j];
 #pragma unroll
                         for (int r = 0; r < 16; ++r) {
-                            const int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                            const int row = m0 + rowb + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
                             if (row < M && col < N) dst[(int64_t)row * N + col] = total[i][j][r];
                         }
                     }
             }
         } else if (SWI && pass == 0) {
 #pragma unroll
-            for (int i = 0; i < 2; ++i)
+            for (int i = 0; i < IM; ++i)
 #pragma unroll
-                for (int j = 0; j < 2; ++j)
+                for (int j = 0; j < JN; ++j)
 #pragma unroll
                     for (int r = 0; r < 16; r += 2) {
                         const bf16_t g0 = f2bf(silu(rbf(total[i][j][r]))), g1 = f2bf(silu(rbf(total[i][j][r + 1])));
@@ -692,13 +708,13 @@ gemm2_w4_kernel(const bf16_t* __restrict__ A, int lda, int M, const uint4* __res
     }
     if constexpr (SPLIT) return;
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < IM; ++i)
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
+        for (int j = 0; j < JN; ++j) {
             const int col = n0 + c_row[j];
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+                const int row = m0 + rowb + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
                 if (row < M && col < N) {
                     bf16_t o;
                     if (SWI) {
