@@ -81,10 +81,12 @@ int parrot_w4_gemv(const void* packed, const void* packed2, const void* x, int l
                    const void* bias, const void* residual, int ldr, void* out, int ldo, int N,
                    int K, int group, int epilogue, const parrot_norm_t* norm, void* stream);
 /* same contract for any M (prefill) on the matrix cores (v_mfma_f32_32x32x16_bf16; the int4 rows are expanded to
- * bf16 in LDS).  M <= 8 forwards to the GEMV.  For M > 8 the norm must already be applied (norm == NULL) and
- * `workspace` holds parrot_gemm_workspace_floats(M, N, K, group, epilogue) floats: the per-group activation sums (int4)
- * and, for launches with too few tiles to fill the chip (short prompts), the split-K partial results that a second
- * stage sums in a fixed order.  group = 0 asks for the bf16 GEMM's needs.                                      */
+ * bf16 in LDS).  M <= 8 forwards to the GEMV.  For M > 8 a norm is taken for groups of 64 / 128 with K % group == 0 and
+ * K <= 16384 (one launch writes the normalised rows and their per-group sums; PARROT_EUNSUPPORTED otherwise: apply
+ * parrot_rmsnorm / parrot_layernorm first and pass norm == NULL), and
+ * `workspace` holds parrot_gemm_workspace_floats(M, N, K, group, epilogue) floats: the normalised rows of a fused norm,
+ * the per-group activation sums (int4) and, for launches with too few tiles to fill the chip (short prompts), the
+ * split-K partial results that a second stage sums in a fixed order.  group = 0 asks for the bf16 GEMM's needs.   */
 int64_t parrot_gemm_workspace_floats(int M, int N, int K, int group, int epilogue);
 int parrot_w4_gemm(const void* packed, const void* packed2, const void* x, int ldx, int M,
                    const void* bias, const void* residual, int ldr, void* out, int ldo, int N,

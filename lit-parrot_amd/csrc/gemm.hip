@@ -386,6 +386,10 @@ static int gemm_launch(int kid, const void* Wp, const void* W2p, const void* x, 
     return launch_splitk_epilogue((const float*)part, (const float*)part2, ksplit, M, N, (const bf16_t*)bias, (const bf16_t*)residual, ldr, (bf16_t*)out, ldo, epilogue, st);
 }
 
+// norm + per-group sums of a prompt's rows in one launch (norm.hip)
+bool norm_xsum_takes(const NormArgs& na, int d, int G);
+int norm_xsum_launch(const NormArgs& na, const void* x, int ldx, void* xn, int ldo, int M, int Mpad, int d, int G, float* xs, hipStream_t st);
+
 // second-generation bf16 kernel (gemm2.hip)
 int gemm2_ksplit(int M, int N, int K);
 bool gemm2_enabled();
@@ -396,7 +400,7 @@ int gemm2_w4_ksplit(int M, int N, int K, const W4Plan& plan);
 int64_t gemm2_w4_xs_floats(int M, const W4Plan& plan);
 int gemm2_w4_launch(const void* Wq, const void* Wq2, const void* x, int ldx, int M, const void* bias, const void* residual, int ldr,
                     void* out, int ldo, int N, int K, int epilogue, float* workspace, const W4Plan& plan, hipStream_t st, int* ksplit_out,
-                    float** part_out, float** part2_out, const void* code);
+                    float** part_out, float** part2_out, const void* code, bool have_xs);
 static bool gemm2_takes(int K, int ldx, int epilogue, const void* W, const void* x) {
     return gemm2_enabled() && epilogue != PARROT_EPI_SWIGLU && K % 64 == 0 && ldx % 8 == 0 && aligned16(W) && aligned16(x);
 }
@@ -428,7 +432,8 @@ int64_t parrot_gemm_workspace_floats(int M, int N, int K, int group, int epilogu
         W4Plan plan;
         if (w4_make_plan(N, K, group, &plan) == PARROT_OK && gemm2_w4_takes(plan, K)) {
             const int ks2 = gemm2_w4_ksplit(M, N, K, plan);
-            const int64_t n2 = gemm2_w4_xs_floats(M, plan) + (ks2 > 1 ? (int64_t)ks2 * M * N * (epilogue == PARROT_EPI_SWIGLU ? 2 : 1) : 0);
+            int64_t n2 = gemm2_w4_xs_floats(M, plan) + (ks2 > 1 ? (int64_t)ks2 * M * N * (epilogue == PARROT_EPI_SWIGLU ? 2 : 1) : 0);
+            if (plan.Gs == 2 || plan.Gs == 4) n2 += ((int64_t)M * K + 1) / 2;  // room for the normalised rows of a fused norm (parrot_w4_gemm)
             if (n2 > n) n = n2;
         }
     }
@@ -464,18 +469,34 @@ int parrot_w4_gemm(const void* packed, const void* packed2, const void* x, int l
         return parrot_w4_gemv(packed, packed2, x, ldx, M, bias, residual, ldr, out, ldo, N, K, group, epilogue, norm, stream);
     int rc = check_linear_args("w4_gemm", packed, packed2, x, ldx, M, residual, ldr, out, ldo, N, K, epilogue);
     if (rc != PARROT_OK) return rc;
-    PARROT_UNSUPPORTED(norm == nullptr || norm->kind == 0, "w4_gemm: apply the norm to the rows first (parrot_rmsnorm / parrot_layernorm)");
     PARROT_REQUIRE(workspace != nullptr, "w4_gemm: workspace of parrot_gemm_workspace_floats(M, N, K, group, epilogue) floats required");
     PARROT_UNSUPPORTED(!(epilogue == PARROT_EPI_SWIGLU && bias), "w4_gemm: SWIGLU epilogue takes no bias");
     W4Plan plan;
     rc = w4_make_plan(N, K, group, &plan);
     if (rc != PARROT_OK) return rc;
     hipStream_t st = (hipStream_t)stream;
+    NormArgs na;
+    rc = make_norm_args(norm, K, &na);
+    if (rc != PARROT_OK) return rc;
+    const bool fused_norm = na.kind != 0;
+    if (fused_norm) {
+        // the norm of the prompt's rows AND the per-group sums of its output in ONE launch in front of the GEMM (instead of
+        // parrot_rmsnorm + the activation-sum pre-pass): the normalised rows go to the head of the workspace
+        PARROT_UNSUPPORTED(gemm2_w4_takes(plan, K) && ldx % 8 == 0 && norm_xsum_takes(na, K, plan.Gs * 32),
+                           "w4_gemm: the fused norm takes groups of 64 / 128 on the LDS-DMA kernel; apply the norm to the rows first "
+                           "(parrot_rmsnorm / parrot_layernorm) for K=%d group=%d", K, group);
+        const int Mpad = (M + 127) / 128 * 128;
+        bf16_t* xn = reinterpret_cast<bf16_t*>(workspace);
+        float* ws2 = reinterpret_cast<float*>(workspace) + ((int64_t)M * K + 1) / 2;
+        rc = norm_xsum_launch(na, x, ldx, xn, K, M, Mpad, K, plan.Gs * 32, ws2, st);
+        if (rc != PARROT_OK) return rc;
+        x = xn, ldx = K, workspace = ws2;
+    }
     if (gemm2_w4_takes(plan, K) && ldx % 8 == 0) {
         int ks = 1;
         float *part = nullptr, *part2 = nullptr;
         rc = gemm2_w4_launch(packed, packed2, x, ldx, M, bias, residual, ldr, out, ldo, N, K, epilogue, (float*)workspace, plan, st, &ks,
-                             &part, &part2, nullptr);
+                             &part, &part2, nullptr, fused_norm);
         if (rc != PARROT_OK || ks == 1) return rc;
         const int64_t mn = (int64_t)M * N;
         return launch_splitk_epilogue((const float*)part, (const float*)part2, ks, M, N, (const bf16_t*)bias, (const bf16_t*)residual, ldr, (bf16_t*)out, ldo, epilogue, st);
@@ -511,7 +532,7 @@ int parrot_w4c_gemm(const void* packed, const void* packed2, const void* code16_
     int ks = 1;
     float *part = nullptr, *part2 = nullptr;
     rc = gemm2_w4_launch(packed, packed2, x, ldx, M, bias, residual, ldr, out, ldo, N, K, epilogue, (float*)workspace, plan, st, &ks, &part,
-                         &part2, code16_bf16);
+                         &part2, code16_bf16, false);
     if (rc != PARROT_OK || ks == 1) return rc;
     const int64_t mn = (int64_t)M * N;
     return launch_splitk_epilogue((const float*)part, (const float*)part2, ks, M, N, (const bf16_t*)bias, (const bf16_t*)residual, ldr, (bf16_t*)out, ldo, epilogue, st);

@@ -766,11 +766,11 @@ int64_t gemm2_w4_xs_floats(int M, const W4Plan& plan) { return (int64_t)((M + G2
 
 int gemm2_w4_launch(const void* Wq, const void* Wq2, const void* x, int ldx, int M, const void* bias, const void* residual, int ldr,
                     void* out, int ldo, int N, int K, int epilogue, float* workspace, const W4Plan& plan, hipStream_t st, int* ksplit_out,
-                    float** part_out, float** part2_out, const void* code) {
+                    float** part_out, float** part2_out, const void* code, bool have_xs) {
     const int Mpad = (M + G2M - 1) / G2M * G2M;
     const int64_t nxs = code ? 0 : (int64_t)Mpad * plan.ngroups;  // codebook weights need no activation sums
     int rc = PARROT_OK;
-    if (!code)
+    if (!code && !have_xs)  // (have_xs: the caller's fused norm wrote the sums at the head of the workspace)
         rc = launch(K_GEMM_XSUM, gemm2_xsum_kernel, dim3((unsigned)((nxs * 16 + 255) / 256)), dim3(256), 0, st, (const bf16_t*)x, ldx, M, Mpad, K,
                     plan.Gs * 32, plan.ngroups, workspace);
     if (rc != PARROT_OK) return rc;

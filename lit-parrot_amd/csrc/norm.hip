@@ -25,12 +25,19 @@ __device__ __forceinline__ float block_sum(float v, float* sh) {
     return t;
 }
 
-template <bool RMS>
+// XS: also write the per-group sums of the OUTPUT row (the rounded bf16 values) the int4 prompt GEMM folds its zero points with
+// (gemm2.hip: sum_g(x), layout [group][Mpad]) - the same 16-lane butterfly as gemm2_xsum_kernel, bit for bit, without its
+// launch.  xs_lanes = group / 8 (8 or 16 lanes of consecutive 16-byte chunks share a group); rows [M, Mpad) get zeros.
+template <bool RMS, bool XS>
 __global__ void __launch_bounds__(kNormThreads)
 norm_kernel(const bf16_t* __restrict__ x, int ldx, const bf16_t* __restrict__ weight, const bf16_t* __restrict__ bias,
-            bf16_t* __restrict__ out, int ldo, int d, float eps, int rsqrt_mode) {
+            bf16_t* __restrict__ out, int ldo, int d, float eps, int rsqrt_mode, int M, int Mpad, int xs_lanes, float* __restrict__ xs) {
     __shared__ float sh[kNormThreads / 64];
     const int chunks = d >> 3;
+    if (XS && (int)blockIdx.x >= M) {  // padding row of the last 128-row tile
+        for (int g = threadIdx.x; g < chunks / xs_lanes; g += kNormThreads) xs[(int64_t)g * Mpad + blockIdx.x] = 0.f;
+        return;
+    }
     const uint4* xp = reinterpret_cast<const uint4*>(x + (int64_t)blockIdx.x * ldx);
     uint4 v[kNormV];
     float s = 0.f;
@@ -80,6 +87,8 @@ norm_kernel(const bf16_t* __restrict__ x, int ldx, const bf16_t* __restrict__ we
 #pragma unroll
     for (int i = 0; i < kNormV; ++i) {
         const int c = threadIdx.x + i * kNormThreads;
+        float part = 0.f;
+        if (XS && i * kNormThreads >= chunks) break;  // (uniform: the butterfly below runs on whole waves)
         if (c < chunks) {
             const uint4 w4 = wp[c];
             const uint32_t dw[4] = {v[i].x, v[i].y, v[i].z, v[i].w};
@@ -103,6 +112,14 @@ norm_kernel(const bf16_t* __restrict__ x, int ldx, const bf16_t* __restrict__ we
                 o[j] = (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16);
             }
             op[c] = make_uint4(o[0], o[1], o[2], o[3]);
+            if (XS) part = (bflo(o[0]) + bfhi(o[0])) + (bflo(o[1]) + bfhi(o[1])) + (bflo(o[2]) + bfhi(o[2])) + (bflo(o[3]) + bfhi(o[3]));
+        }
+        if (XS) {
+            part += __shfl_xor(part, 1);
+            part += __shfl_xor(part, 2);
+            part += __shfl_xor(part, 4);
+            if (xs_lanes == 16) part += __shfl_xor(part, 8);
+            if (c < chunks && (c & (xs_lanes - 1)) == 0) xs[(int64_t)(c / xs_lanes) * Mpad + blockIdx.x] = part;
         }
     }
 }
@@ -117,6 +134,18 @@ static int norm_check(const char* who, const void* x, int ldx, const void* w, co
     return PARROT_OK;
 }
 
+// the norm of a prompt's rows + their per-group sums in one launch (parrot_w4_gemm with a norm argument)
+bool norm_xsum_takes(const NormArgs& na, int d, int G) { return (na.kind == 1 || na.kind == 2) && (G == 64 || G == 128) && d % G == 0 && d <= kNormThreads * 8 * kNormV; }
+int norm_xsum_launch(const NormArgs& na, const void* x, int ldx, void* xn, int ldo, int M, int Mpad, int d, int G, float* xs, hipStream_t st) {
+    const int rc = norm_check("w4_gemm (norm)", x, ldx, na.weight, xn, ldo, M, d);
+    if (rc != PARROT_OK) return rc;
+    if (na.kind == 1)
+        return launch(K_RMSNORM, norm_kernel<true, true>, dim3(Mpad), dim3(kNormThreads), 0, st, (const bf16_t*)x, ldx, na.weight,
+                      (const bf16_t*)nullptr, (bf16_t*)xn, ldo, d, na.eps, na.rsqrt_mode, M, Mpad, G / 8, xs);
+    return launch(K_LAYERNORM, norm_kernel<false, true>, dim3(Mpad), dim3(kNormThreads), 0, st, (const bf16_t*)x, ldx, na.weight, na.bias,
+                  (bf16_t*)xn, ldo, d, na.eps, 0, M, Mpad, G / 8, xs);
+}
+
 }  // namespace parrot
 
 using namespace parrot;
@@ -127,8 +156,8 @@ int parrot_rmsnorm(const void* x, int ldx, const void* weight, void* out, int ld
                    int rsqrt_mode, void* stream) {
     const int rc = norm_check("rmsnorm", x, ldx, weight, out, ldo, M, d);
     if (rc != PARROT_OK) return rc;
-    return launch(K_RMSNORM, norm_kernel<true>, dim3(M), dim3(kNormThreads), 0, (hipStream_t)stream, (const bf16_t*)x, ldx,
-                  (const bf16_t*)weight, (const bf16_t*)nullptr, (bf16_t*)out, ldo, d, eps, rsqrt_mode);
+    return launch(K_RMSNORM, norm_kernel<true, false>, dim3(M), dim3(kNormThreads), 0, (hipStream_t)stream, (const bf16_t*)x, ldx,
+                  (const bf16_t*)weight, (const bf16_t*)nullptr, (bf16_t*)out, ldo, d, eps, rsqrt_mode, M, M, 16, (float*)nullptr);
 }
 
 int parrot_layernorm(const void* x, int ldx, const void* weight, const void* bias, void* out, int ldo, int M, int d,
@@ -136,8 +165,8 @@ int parrot_layernorm(const void* x, int ldx, const void* weight, const void* bia
     const int rc = norm_check("layernorm", x, ldx, weight, out, ldo, M, d);
     if (rc != PARROT_OK) return rc;
     PARROT_REQUIRE(!bias || aligned16(bias), "layernorm: bias must be 16-byte aligned");
-    return launch(K_LAYERNORM, norm_kernel<false>, dim3(M), dim3(kNormThreads), 0, (hipStream_t)stream, (const bf16_t*)x,
-                  ldx, (const bf16_t*)weight, (const bf16_t*)bias, (bf16_t*)out, ldo, d, eps, 0);
+    return launch(K_LAYERNORM, norm_kernel<false, false>, dim3(M), dim3(kNormThreads), 0, (hipStream_t)stream, (const bf16_t*)x,
+                  ldx, (const bf16_t*)weight, (const bf16_t*)bias, (bf16_t*)out, ldo, d, eps, 0, M, M, 16, (float*)nullptr);
 }
 
 }  // extern "C"

@@ -128,10 +128,18 @@ def w4_repack(quant_weight: torch.Tensor, scales: torch.Tensor, zeros: torch.Ten
                                        stream()), "parrot_w4_repack")
 
 
+W4_GEMM_FUSED_NORM = True  # (False: the stand-alone norm kernels in front of the prompt GEMM - tests compare the two)
+
+
 def w4_linear(packed: torch.Tensor, N: int, K: int, group: int, x: torch.Tensor, out: torch.Tensor, *, bias=None,
               epilogue=EPI_NONE, residual=None, packed2=None, norm: Optional[Norm] = None) -> torch.Tensor:
     _rows(x, "w4_linear"), _rows(out, "w4_linear")
-    x, norm = _prenorm(x, norm)
+    # prompts on groups of 64 / 128: parrot_w4_gemm applies the norm itself - one launch writes the normalised rows AND the per-group
+    # sums the int4 kernel folds its zero points with (instead of parrot_rmsnorm + the activation-sum pre-pass)
+    fused = (norm is not None and W4_GEMM_FUSED_NORM and x.shape[0] > GEMV_MAX_ROWS and group in (64, 128) and K % group == 0
+             and K <= 16384 and x.stride(0) % 8 == 0)
+    if not fused:
+        x, norm = _prenorm(x, norm)
     M = x.shape[0]
     if x.shape[1] != K or out.shape[1] != N:
         raise ParrotHipError(f"w4_linear: x {tuple(x.shape)} / out {tuple(out.shape)} do not match N={N} K={K}")

@@ -229,6 +229,38 @@ def test_w4_gemm_lds_dma_kernel_unsplit_launch_and_single_step_groups(group, epi
     assert torch.all(out[M] == 7.0), "wrote past the last row"
 
 
+@pytest.mark.parametrize("kind", [1, 2])
+@pytest.mark.parametrize("M,N,K,group", [(200, 256, 4096, 128), (129, 96, 512, 64), (640, 2048, 11008, 128)])
+def test_w4_gemm_with_the_norm_fused_in_front(kind, M, N, K, group):
+    """parrot_w4_gemm with a norm argument (one launch: normalised rows + their per-group sums) returns the bits of the stand-alone
+    norm kernel followed by the GEMM's own activation-sum pre-pass - RMSNorm and LayerNorm, split and unsplit launches, a ragged
+    last row tile, groups of 64 and 128."""
+    from lit_parrot_amd import ops
+
+    g = gen(51)
+    x = (torch.randn(M, K, generator=g) * 1.5 + 0.1).to(BF).to(DEV)
+    w = (1 + 0.1 * torch.randn(K, generator=g)).to(BF).to(DEV)
+    b = (0.1 * torch.randn(K, generator=g)).to(BF).to(DEV) if kind == 2 else None
+    qw, s, z, tc, Wd = make_w4(N, K, group, 52)
+    lin = w4_module(qw, s, z, N, K, group)
+    norm = ops.Norm(kind, w, b, 1e-5)
+    outs = []
+    for fused in (True, False):
+        ops.W4_GEMM_FUSED_NORM = fused
+        try:
+            out = torch.empty((M + 1, N), dtype=BF, device=DEV).fill_(3.0)
+            lin.hip_linear(x, out[:M], norm=norm)
+            outs.append(out)
+        finally:
+            ops.W4_GEMM_FUSED_NORM = True
+    assert torch.equal(outs[0], outs[1]), f"{int((outs[0] != outs[1]).sum())} elements differ between the fused and the stand-alone norm"
+    assert torch.all(outs[0][M] == 3.0)
+    xn = torch.empty_like(x)
+    (ops.rmsnorm(x, w, 1e-5, xn) if kind == 1 else ops.layernorm(x, w, b, 1e-5, xn))
+    want = rbf(xn.cpu().double() @ Wd.t())
+    assert_bf16_close(outs[0][:M], want, ulps=1, atol=2e-2, what="w4 gemm behind a fused norm")
+
+
 @pytest.mark.parametrize("epi", [EPI_NONE, EPI_SWIGLU])
 def test_w4_gemm_long_unsplit_loop_repeats_bit_identically(epi):
     """The unsplit int4 prompt kernel over a long K loop (32 steps, a slab crossing), called four times on the same operands:
